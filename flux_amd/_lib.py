@@ -1,0 +1,102 @@
+"""ctypes binding of the C ABI in include/flux_abi.h (flux_amd/libflux_hip.so).
+
+There is no fallback: if the library is missing or a symbol is absent, importing
+this module raises.  Compute entry points fail with FluxError when no HIP
+device is visible.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflux_hip.so")
+
+FLUX_OK = 0
+E_INVALID, E_DEVICE, E_NOMEM, E_IO = -1, -2, -3, -4
+SHAPE_SPHERE, SHAPE_PLANE = 0, 1
+MAT_MATTE, MAT_EMISSIVE, MAT_REFLECTIVE, MAT_GLOSSY = 0, 1, 2, 3
+KERNEL_DEFAULT, KERNEL_STATIC, KERNEL_REFILL = 0, 1, 2
+TABLE_PIXEL, TABLE_DISC, TABLE_HEMI = 0, 1, 2
+
+
+class FluxMaterial(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("color", C.c_double * 3),
+                ("ambient", C.c_double * 3), ("k", C.c_double), ("exponent", C.c_double)]
+
+
+class FluxShape(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("invert", C.c_int32), ("p", C.c_double * 3), ("n", C.c_double * 3),
+                ("radius", C.c_double), ("material", FluxMaterial)]
+
+
+class FluxSceneDesc(C.Structure):
+    _fields_ = [("scene_name", C.c_char_p), ("image_width", C.c_uint64), ("image_height", C.c_uint64),
+                ("pixel_size", C.c_double), ("background", C.c_double * 3), ("eye", C.c_double * 3),
+                ("look_at", C.c_double * 3), ("up", C.c_double * 3), ("zoom_factor", C.c_double),
+                ("view_plane_distance", C.c_double), ("focal_distance", C.c_double),
+                ("lens_radius", C.c_double), ("num_shapes", C.c_uint64), ("shapes", C.POINTER(FluxShape))]
+
+
+class FluxJobCfg(C.Structure):
+    _fields_ = [("sample_root", C.c_uint64), ("max_trace_depth", C.c_uint64),
+                ("rows_per_work_unit", C.c_uint64)]
+
+
+class FluxWorkUnit(C.Structure):
+    _fields_ = [("row_start", C.c_uint64), ("row_end", C.c_uint64)]
+
+
+class FluxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"flux error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/flux_abi.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "flux_abi_version": (C.c_uint32, []),
+    "flux_last_error": (C.c_char_p, []),
+    "flux_device_count": (C.c_int, []),
+    "flux_ctx_create": (C.c_int, [C.POINTER(FluxSceneDesc), C.POINTER(FluxJobCfg), C.c_uint64, C.c_int,
+                                  C.POINTER(_P)]),
+    "flux_ctx_destroy": (None, [_P]),
+    "flux_render_rows": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]),
+    "flux_render_rows_device": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P]),
+    "flux_ctx_set_kernel": (C.c_int, [_P, C.c_int]),
+    "flux_ctx_last_kernel_ms": (C.c_double, [_P]),
+    "flux_ctx_enable_stats": (C.c_int, [_P, C.c_int]),
+    "flux_ctx_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
+    "flux_ctx_copy_table": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.c_uint64]),
+    "flux_ctx_copy_row_perm": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_int32), C.c_uint64]),
+    "flux_ctx_camera_basis": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "flux_ctx_device_bytes": (C.c_uint64, [_P]),
+    "flux_work_units": (C.c_int64, [C.c_uint64, C.c_uint64, C.POINTER(FluxWorkUnit), C.c_uint64]),
+    "flux_write_ppm": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.c_uint64, C.c_uint64,
+                                 C.POINTER(C.c_uint8)]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m flux_amd.build` "
+            "(the renderer has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    return (lib.flux_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc < 0:
+        raise FluxError(rc, last_error())
+    return rc

@@ -1,0 +1,68 @@
+"""Build the in-tree native libraries.
+
+* ``flux_amd/libflux_hip.so`` -- the product: HIP kernels + C ABI (include/flux_abi.h),
+  cross-compiled for gfx950 with hipcc (works without a GPU).
+* ``oracle/libflux_oracle.so`` -- the CPU oracle (test infrastructure only), gcc.
+
+The ``.so`` files are git-ignored but travel with the gpurun snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "flux_amd", "csrc")
+HIP_SOURCES = ["abi.hip", "tables.hip", "render.hip"]
+HIP_HEADERS = ["flux_device.h", "flux_rng.h", "flux_tables.h"]
+HIP_LIB = os.path.join(ROOT, "flux_amd", "libflux_hip.so")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libflux_oracle.so")
+
+# -ffp-contract=off: the kernels keep the reference's operation order and never
+# fuse a*b+c (rustc does not contract); see DESIGN.md "Numerics".
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+             "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(ROOT, "include", "flux_abi.h")]
+    if not force and not _newer(HIP_LIB, deps):
+        return HIP_LIB
+    cmd = [_hipcc()] + HIP_FLAGS + ["-o", HIP_LIB] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return HIP_LIB
+
+
+def build_oracle(force=False, verbose=False):
+    deps = [os.path.join(ORACLE_DIR, f) for f in ("flux_oracle.c", "flux_oracle.h", "Makefile")]
+    if not force and not _newer(ORACLE_LIB, deps):
+        return ORACLE_LIB
+    subprocess.run(["make", "-C", ORACLE_DIR] + (["-B"] if force else []), check=True,
+                   stdout=None if verbose else subprocess.DEVNULL)
+    return ORACLE_LIB
+
+
+def build_all(force=False, verbose=False):
+    return build_hip(force, verbose), build_oracle(force, verbose)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,474 @@
+// abi.hip -- implementation of include/flux_abi.h (the drop-in boundary).
+//
+// flux_ctx_create  = Scene::from_data (scene.rs:128-154) + Camera::new
+//                    (trace.rs:26-42) as called from workers.rs:46-54
+// flux_render_rows = Camera::render (trace.rs:53-97) as called from workers.rs:60
+// There is no CPU fallback: without a usable HIP device every compute entry
+// point fails with FLUX_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/flux_abi.h"
+#include "flux_device.h"
+#include "flux_tables.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? FLUX_E_NOMEM : FLUX_E_DEVICE, "%s: %s", \
+                        #expr, hipGetErrorString(e_));                                      \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+struct flux_ctx {
+    int device = 0;
+    flux::RenderParams rp{};  // camera + table pointers; work fields set per launch
+    uint64_t seed = 0;
+    uint32_t n = 0, N = 0, D = 0, S = 0, W = 0, H = 0;
+    flux::DevShape *d_shapes = nullptr;
+    flux::DevMaterial *d_mats = nullptr;
+    double2 *d_pix = nullptr, *d_disc = nullptr;
+    double *d_hemi = nullptr;
+    int32_t *d_rowperm = nullptr;
+    unsigned long long *d_stats = nullptr;
+    bool stats_on = false;
+    int variant = FLUX_KERNEL_DEFAULT;
+    // scratch framebuffer for the host-output path
+    double *d_out = nullptr;
+    size_t d_out_doubles = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    uint64_t device_bytes = 0;
+    double U[3], V[3], Wv[3];
+};
+
+extern "C" {
+
+uint32_t flux_abi_version(void) { return FLUX_ABI_VERSION; }
+
+const char *flux_last_error(void) { return g_last_error.c_str(); }
+
+int flux_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static void free_ctx(flux_ctx *c) {
+    if (!c) return;
+    DeviceGuard g(c->device);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    (void)hipFree(c->d_shapes);
+    (void)hipFree(c->d_mats);
+    (void)hipFree(c->d_pix);
+    (void)hipFree(c->d_disc);
+    (void)hipFree(c->d_hemi);
+    (void)hipFree(c->d_rowperm);
+    (void)hipFree(c->d_stats);
+    (void)hipFree(c->d_out);
+    delete c;
+}
+
+void flux_ctx_destroy(flux_ctx *ctx) { free_ctx(ctx); }
+
+static void normalize3(const double in[3], double out[3]) {
+    double len = std::sqrt(in[0] * in[0] + in[1] * in[1] + in[2] * in[2]);
+    out[0] = in[0] / len;
+    out[1] = in[1] / len;
+    out[2] = in[2] / len;
+}
+static void cross3(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint64_t seed, int device,
+                    flux_ctx **out) {
+    if (!scene || !cfg || !out) return fail(FLUX_E_INVALID, "flux_ctx_create: null argument");
+    *out = nullptr;
+    if (cfg->sample_root < 1 || cfg->sample_root > 4096)
+        return fail(FLUX_E_INVALID, "sample_root must be in [1,4096], got %llu",
+                    (unsigned long long)cfg->sample_root);
+    if (cfg->max_trace_depth < 1 || cfg->max_trace_depth > 16)
+        return fail(FLUX_E_INVALID, "max_trace_depth must be in [1,16], got %llu",
+                    (unsigned long long)cfg->max_trace_depth);
+    if (scene->image_width < 1 || scene->image_height < 1 || scene->image_width > 65535 ||
+        scene->image_height > (1u << 20))
+        return fail(FLUX_E_INVALID, "image size %llux%llu out of range",
+                    (unsigned long long)scene->image_width, (unsigned long long)scene->image_height);
+    if (scene->num_shapes > 0 && !scene->shapes)
+        return fail(FLUX_E_INVALID, "num_shapes > 0 but shapes is null");
+    if (scene->num_shapes > 4096)
+        return fail(FLUX_E_INVALID, "flat shape list limited to 4096 shapes, got %llu",
+                    (unsigned long long)scene->num_shapes);
+    for (uint64_t i = 0; i < scene->num_shapes; i++) {
+        const flux_shape &s = scene->shapes[i];
+        if (s.kind != FLUX_SHAPE_SPHERE && s.kind != FLUX_SHAPE_PLANE)
+            return fail(FLUX_E_INVALID, "shape %llu: unknown kind %d", (unsigned long long)i, s.kind);
+        if (s.material.kind < FLUX_MAT_MATTE || s.material.kind > FLUX_MAT_GLOSSY)
+            return fail(FLUX_E_INVALID, "shape %llu: unknown material kind %d", (unsigned long long)i,
+                        s.material.kind);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(FLUX_E_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(FLUX_E_INVALID, "device %d out of range [0,%d)", device, ndev);
+
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(FLUX_E_DEVICE, "hipSetDevice(%d) failed", device);
+
+    flux_ctx *c = new (std::nothrow) flux_ctx();
+    if (!c) return fail(FLUX_E_NOMEM, "host allocation failed");
+    c->device = device;
+    c->seed = seed;
+    c->n = (uint32_t)cfg->sample_root;
+    c->N = c->n * c->n;
+    c->D = (uint32_t)cfg->max_trace_depth;
+    c->W = (uint32_t)scene->image_width;
+    c->H = (uint32_t)scene->image_height;
+    c->S = c->W;  // workers.rs:50: num_sets = image_width
+
+    // ---- Scene::from_data: per-shape constants -------------------------------
+    const size_t ns = (size_t)scene->num_shapes;
+    std::vector<flux::DevShape> shapes(ns ? ns : 1);
+    std::vector<flux::DevMaterial> mats(ns ? ns : 1);
+    std::memset(shapes.data(), 0, shapes.size() * sizeof(flux::DevShape));
+    std::memset(mats.data(), 0, mats.size() * sizeof(flux::DevMaterial));
+    for (size_t i = 0; i < ns; i++) {
+        const flux_shape &s = scene->shapes[i];
+        flux::DevShape &d = shapes[i];
+        d.kind = s.kind;
+        d.px = s.p[0];
+        d.py = s.p[1];
+        d.pz = s.p[2];
+        if (s.kind == FLUX_SHAPE_SPHERE) {
+            d.radius = s.radius;
+            d.rr = s.radius * s.radius;
+            d.inv = s.invert ? -1.0 : 1.0;
+            // Sphere::new: shapes.rs:154-169
+            d.c0x = s.p[0] - s.radius;
+            d.c0y = s.p[1] - s.radius;
+            d.c0z = s.p[2] - s.radius;
+            d.c1x = s.p[0] + s.radius;
+            d.c1y = s.p[1] + s.radius;
+            d.c1z = s.p[2] + s.radius;
+        } else {
+            d.c0x = s.n[0];
+            d.c0y = s.n[1];
+            d.c0z = s.n[2];
+        }
+        // material_from_data: scene.rs:87-125
+        const flux_material &m = s.material;
+        flux::DevMaterial &dm = mats[i];
+        dm.kind = m.kind;
+        dm.exponent = m.exponent;
+        dm.inv_e1 = 1.0 / (m.exponent + 1.0);
+        for (int ch = 0; ch < 3; ch++) {
+            double v = m.color[ch] * m.k;
+            if (m.kind == FLUX_MAT_MATTE) v = v * flux::kInvPi;  // brdf.rs:30
+            (&dm.fr)[ch] = v;
+        }
+    }
+
+    // ---- CameraBasis::new: scene.rs:28-35 --------------------------------------
+    double em[3] = {scene->eye[0] - scene->look_at[0], scene->eye[1] - scene->look_at[1],
+                    scene->eye[2] - scene->look_at[2]};
+    double upxw[3];
+    normalize3(em, c->Wv);
+    cross3(scene->up, c->Wv, upxw);
+    normalize3(upxw, c->U);
+    cross3(c->Wv, c->U, c->V);
+
+    flux::RenderParams &rp = c->rp;
+    rp.ex = scene->eye[0];
+    rp.ey = scene->eye[1];
+    rp.ez = scene->eye[2];
+    rp.Ux = c->U[0];
+    rp.Uy = c->U[1];
+    rp.Uz = c->U[2];
+    rp.Vx = c->V[0];
+    rp.Vy = c->V[1];
+    rp.Vz = c->V[2];
+    rp.Wx = c->Wv[0];
+    rp.Wy = c->Wv[1];
+    rp.Wz = c->Wv[2];
+    rp.aps = scene->pixel_size / scene->zoom_factor;                  // trace.rs:60
+    rp.half_w = (double)c->W * 0.5;                                   // trace.rs:57
+    rp.half_h = (double)c->H * 0.5;                                   // trace.rs:56
+    rp.factor = scene->focal_distance / scene->view_plane_distance;   // trace.rs:45
+    rp.focal = scene->focal_distance;
+    rp.lens_radius = scene->lens_radius;
+    rp.bgr = scene->background[0];
+    rp.bgg = scene->background[1];
+    rp.bgb = scene->background[2];
+    rp.pixel_denom = 1.0 / (double)((uint64_t)c->n * c->n);           // trace.rs:59
+    rp.img_w = (int32_t)c->W;
+    rp.img_h = (int32_t)c->H;
+    rp.n_shapes = (int32_t)ns;
+    rp.max_depth = (int32_t)c->D;
+    rp.nsamp = c->N;
+    rp.num_sets = c->S;
+
+    // ---- HBM allocations ------------------------------------------------------
+    const size_t pix_bytes = (size_t)c->S * c->N * sizeof(double2);
+    const size_t hemi_bytes = (size_t)c->S * c->D * c->N * 3 * sizeof(double);
+    const size_t perm_bytes = (size_t)c->H * c->S * sizeof(int32_t);
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void **p, size_t bytes) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(p, bytes);
+        if (e == hipSuccess) c->device_bytes += bytes;
+    };
+    alloc((void **)&c->d_shapes, shapes.size() * sizeof(flux::DevShape));
+    alloc((void **)&c->d_mats, mats.size() * sizeof(flux::DevMaterial));
+    alloc((void **)&c->d_pix, pix_bytes);
+    alloc((void **)&c->d_disc, pix_bytes);
+    alloc((void **)&c->d_hemi, hemi_bytes);
+    alloc((void **)&c->d_rowperm, perm_bytes);
+    alloc((void **)&c->d_stats, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpy(c->d_shapes, shapes.data(), shapes.size() * sizeof(flux::DevShape), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_mats, mats.data(), mats.size() * sizeof(flux::DevMaterial), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    // ---- MasterSampleSets::new on the device (sampling.rs:13-33) --------------
+    if (e == hipSuccess)
+        e = flux::generate_tables(seed, c->S, c->D, c->n, c->H, c->d_pix, c->d_disc, c->d_hemi, c->d_rowperm, nullptr);
+    if (e != hipSuccess) {
+        int code = fail(e == hipErrorOutOfMemory ? FLUX_E_NOMEM : FLUX_E_DEVICE, "flux_ctx_create: %s",
+                        hipGetErrorString(e));
+        free_ctx(c);
+        return code;
+    }
+    rp.shapes = c->d_shapes;
+    rp.mats = c->d_mats;
+    rp.pix = c->d_pix;
+    rp.disc = c->d_disc;
+    rp.hemi = c->d_hemi;
+    rp.rowperm = c->d_rowperm;
+    rp.stats = nullptr;
+    *out = c;
+    return FLUX_OK;
+}
+
+int flux_ctx_set_kernel(flux_ctx *ctx, int variant) {
+    if (!ctx) return fail(FLUX_E_INVALID, "null context");
+    if (variant < FLUX_KERNEL_DEFAULT || variant > FLUX_KERNEL_REFILL)
+        return fail(FLUX_E_INVALID, "unknown kernel variant %d", variant);
+    ctx->variant = variant;
+    return FLUX_OK;
+}
+
+int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stride, uint64_t num_rows,
+                            void *d_out_rgb, void *hip_stream) {
+    if (!ctx) return fail(FLUX_E_INVALID, "null context");
+    if (num_rows == 0) return FLUX_OK;
+    if (!d_out_rgb) return fail(FLUX_E_INVALID, "null output pointer");
+    if (row_stride < 1) return fail(FLUX_E_INVALID, "row_stride must be >= 1");
+    if (first_row >= ctx->H || first_row + (num_rows - 1) * row_stride >= ctx->H)
+        return fail(FLUX_E_INVALID, "rows %llu + k*%llu (k<%llu) exceed image height %u",
+                    (unsigned long long)first_row, (unsigned long long)row_stride,
+                    (unsigned long long)num_rows, ctx->H);
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(FLUX_E_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    hipStream_t stream = (hipStream_t)hip_stream;
+    flux::RenderParams p = ctx->rp;
+    p.out = (double *)d_out_rgb;
+    p.first_row = (int32_t)first_row;
+    p.row_stride = (int32_t)row_stride;
+    p.num_rows = (int32_t)num_rows;
+    p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
+    HIP_TRY(hipEventRecord(ctx->ev0, stream));
+    HIP_TRY(flux::launch_render(p, ctx->variant, stream));
+    HIP_TRY(hipEventRecord(ctx->ev1, stream));
+    ctx->timed = true;
+    return FLUX_OK;
+}
+
+int flux_render_rows(flux_ctx *ctx, uint64_t row_start, uint64_t row_end, double *out_rgb) {
+    if (!ctx) return fail(FLUX_E_INVALID, "null context");
+    if (!out_rgb) return fail(FLUX_E_INVALID, "null output pointer");
+    if (row_end < row_start || row_end >= ctx->H)
+        return fail(FLUX_E_INVALID, "work unit rows [%llu,%llu] outside image height %u",
+                    (unsigned long long)row_start, (unsigned long long)row_end, ctx->H);
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(FLUX_E_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    const uint64_t rows = row_end - row_start + 1;
+    const size_t doubles = (size_t)rows * ctx->W * 3;
+    if (doubles > ctx->d_out_doubles) {
+        (void)hipFree(ctx->d_out);
+        ctx->d_out = nullptr;
+        ctx->d_out_doubles = 0;
+        HIP_TRY(hipMalloc((void **)&ctx->d_out, doubles * sizeof(double)));
+        ctx->d_out_doubles = doubles;
+    }
+    int rc = flux_render_rows_device(ctx, row_start, 1, rows, ctx->d_out, nullptr);
+    if (rc != FLUX_OK) return rc;
+    HIP_TRY(hipMemcpy(out_rgb, ctx->d_out, doubles * sizeof(double), hipMemcpyDeviceToHost));
+    return FLUX_OK;
+}
+
+double flux_ctx_last_kernel_ms(flux_ctx *ctx) {
+    if (!ctx || !ctx->timed) return -1.0;
+    DeviceGuard guard(ctx->device);
+    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+int flux_ctx_enable_stats(flux_ctx *ctx, int on) {
+    if (!ctx) return fail(FLUX_E_INVALID, "null context");
+    ctx->stats_on = on != 0;
+    return FLUX_OK;
+}
+
+int flux_ctx_stats(flux_ctx *ctx, uint64_t out[8], int reset) {
+    if (!ctx || !out) return fail(FLUX_E_INVALID, "null argument");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long tmp[8];
+    HIP_TRY(hipMemcpy(tmp, ctx->d_stats, sizeof(tmp), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) out[i] = tmp[i];
+    if (reset) HIP_TRY(hipMemset(ctx->d_stats, 0, sizeof(tmp)));
+    return FLUX_OK;
+}
+
+int flux_ctx_copy_table(flux_ctx *ctx, int which, double *out, uint64_t out_doubles) {
+    if (!ctx || !out) return fail(FLUX_E_INVALID, "null argument");
+    DeviceGuard guard(ctx->device);
+    const size_t SN = (size_t)ctx->S * ctx->N;
+    if (which == FLUX_TABLE_PIXEL || which == FLUX_TABLE_DISC) {
+        if (out_doubles < SN * 2) return fail(FLUX_E_INVALID, "output too small: need %zu doubles", SN * 2);
+        HIP_TRY(hipMemcpy(out, which == FLUX_TABLE_PIXEL ? ctx->d_pix : ctx->d_disc, SN * 2 * sizeof(double),
+                          hipMemcpyDeviceToHost));
+        return FLUX_OK;
+    }
+    if (which == FLUX_TABLE_HEMI) {
+        const size_t total = SN * ctx->D * 3;
+        if (out_doubles < total) return fail(FLUX_E_INVALID, "output too small: need %zu doubles", total);
+        double *tmp = nullptr;
+        HIP_TRY(hipMalloc((void **)&tmp, total * sizeof(double)));
+        hipError_t e = flux::hemi_to_aos((size_t)ctx->S * ctx->D, ctx->N, ctx->d_hemi, tmp, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(out, tmp, total * sizeof(double), hipMemcpyDeviceToHost);
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return fail(FLUX_E_DEVICE, "hemi copy: %s", hipGetErrorString(e));
+        return FLUX_OK;
+    }
+    return fail(FLUX_E_INVALID, "unknown table %d", which);
+}
+
+int flux_ctx_copy_row_perm(flux_ctx *ctx, uint64_t row, int32_t *out, uint64_t out_len) {
+    if (!ctx || !out) return fail(FLUX_E_INVALID, "null argument");
+    if (row >= ctx->H) return fail(FLUX_E_INVALID, "row %llu outside image height %u", (unsigned long long)row, ctx->H);
+    if (out_len < ctx->S) return fail(FLUX_E_INVALID, "output too small: need %u entries", ctx->S);
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipMemcpy(out, ctx->d_rowperm + (size_t)row * ctx->S, (size_t)ctx->S * sizeof(int32_t),
+                      hipMemcpyDeviceToHost));
+    return FLUX_OK;
+}
+
+int flux_ctx_camera_basis(flux_ctx *ctx, double uvw[9]) {
+    if (!ctx || !uvw) return fail(FLUX_E_INVALID, "null argument");
+    for (int i = 0; i < 3; i++) {
+        uvw[i] = ctx->U[i];
+        uvw[3 + i] = ctx->V[i];
+        uvw[6 + i] = ctx->Wv[i];
+    }
+    return FLUX_OK;
+}
+
+uint64_t flux_ctx_device_bytes(flux_ctx *ctx) { return ctx ? ctx->device_bytes : 0; }
+
+// ---- host-side pieces of the boundary ------------------------------------------
+
+// Job::work_units: job.rs:65-88
+int64_t flux_work_units(uint64_t image_height, uint64_t rows_per_work_unit, flux_work_unit *out, uint64_t cap) {
+    if (rows_per_work_unit == 0)
+        return fail(FLUX_E_INVALID, "Job row per work unit count invalid: 0");  // job.rs:67-70 panics
+    if (image_height == 0) return fail(FLUX_E_INVALID, "image_height must be >= 1");
+    int64_t count = 0;
+    uint64_t i = 0;
+    while (i < image_height - 1) {  // sic: job.rs:74
+        uint64_t remaining = image_height - i;
+        uint64_t rows = rows_per_work_unit < remaining ? rows_per_work_unit : remaining;
+        if (out && (uint64_t)count < cap) {
+            out[count].row_start = i;
+            out[count].row_end = i + rows - 1;
+        }
+        count++;
+        i += rows;
+    }
+    return count;
+}
+
+static unsigned quantize16(double c) {  // `(c * 65535.99) as u16`: image.rs:50-53 (saturating cast)
+    double v = c * 65535.99;
+    if (!(v > 0.0)) return 0;
+    if (v >= 65535.0) return 65535;
+    return (unsigned)v;
+}
+
+// Image::write: image.rs:43-61
+int flux_write_ppm(const char *path, const double *rgb, uint64_t width, uint64_t height,
+                   const uint8_t *rows_present) {
+    if (!path || !rgb) return fail(FLUX_E_INVALID, "null argument");
+    FILE *f = std::fopen(path, "w");
+    if (!f) return fail(FLUX_E_IO, "cannot open %s for writing", path);
+    std::vector<char> buf(1 << 20);
+    std::setvbuf(f, buf.data(), _IOFBF, buf.size());
+    std::fprintf(f, "P3\n%llu %llu\n65535\n", (unsigned long long)width, (unsigned long long)height);
+    for (uint64_t r = 0; r < height; r++) {
+        const bool present = rows_present ? rows_present[r] != 0 : true;
+        for (uint64_t col = 0; col < width; col++) {
+            if (present) {
+                const double *p = rgb + (r * width + col) * 3;
+                std::fprintf(f, "%u %u %u\n", quantize16(p[0]), quantize16(p[1]), quantize16(p[2]));
+            } else {
+                std::fputs("0 0 0\n", f);
+            }
+        }
+    }
+    int bad = std::ferror(f);
+    if (std::fclose(f) != 0 || bad) return fail(FLUX_E_IO, "write to %s failed", path);
+    return FLUX_OK;
+}
+
+}  // extern "C"

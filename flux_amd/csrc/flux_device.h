@@ -1,0 +1,79 @@
+// flux_device.h -- device-side data layout shared by the table generator, the
+// render kernels and the C-ABI implementation.  See DESIGN.md "Data layout in HBM".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace flux {
+
+constexpr double kTMin = 0.0005;                       // constants.rs:4
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double kInvPi = 1.0 / kPi;                   // constants.rs:5
+
+constexpr int kShapeSphere = 0;
+constexpr int kShapePlane = 1;
+constexpr int kMatMatte = 0;
+constexpr int kMatEmissive = 1;
+constexpr int kMatReflective = 2;
+constexpr int kMatGlossy = 3;
+
+// One shape, 128 B.  The shape loop index is wave-uniform, so these are
+// fetched with scalar loads (s_load_dwordx8/x16) and live in SGPRs.
+struct DevShape {
+    double px, py, pz;     // sphere centre | plane point
+    double radius;         // sphere radius
+    double c0x, c0y, c0z;  // sphere AABB corner0 (Sphere::new, shapes.rs:154-169) | plane normal
+    double rr;             // radius*radius (shapes.rs:179 recomputes it per ray)
+    double c1x, c1y, c1z;  // sphere AABB corner1
+    double inv;            // invert_val: -1 if `invert` else +1 (shapes.rs:181)
+    int32_t kind;
+    int32_t pad0;
+    double pad1[3];
+};
+static_assert(sizeof(DevShape) == 128, "DevShape layout");
+
+// One material per shape (same index), 64 B; gathered per lane after the
+// nearest hit is known.
+struct DevMaterial {
+    // Matte: diffuse_color*kd*INV_PI (brdf.rs:30); Emissive: color*power
+    // (materials.rs:45); Reflective/Glossy: reflect_color*reflect_amount
+    // (brdf.rs:45,76) -- per-material constants the reference recomputes per hit.
+    double fr, fg, fb;
+    double exponent;  // Glossy reflect_exponent
+    double inv_e1;    // 1/(exponent+1) (samplers/src/lib.rs:136)
+    int32_t kind;
+    int32_t pad0;
+    double pad1[2];
+};
+static_assert(sizeof(DevMaterial) == 64, "DevMaterial layout");
+
+// Kernel argument block (by value -> kernarg segment -> scalar loads).
+struct RenderParams {
+    // camera (trace.rs:44-60, scene.rs:28-35)
+    double ex, ey, ez;
+    double Ux, Uy, Uz, Vx, Vy, Vz, Wx, Wy, Wz;
+    double aps;          // adjusted_pixel_size = pixel_size / zoom_factor
+    double half_w, half_h;
+    double factor;       // focal_distance / view_plane_distance
+    double focal, lens_radius;
+    double bgr, bgg, bgb;
+    double pixel_denom;  // 1/(n*n)
+    int32_t img_w, img_h;
+    int32_t n_shapes, max_depth;
+    uint32_t nsamp;      // N = n*n
+    uint32_t num_sets;   // S = image_width
+    // tables in HBM
+    const DevShape *shapes;
+    const DevMaterial *mats;
+    const double2 *pix;   // [S][N] (x,y)                 pixel_sets
+    const double2 *disc;  // [S][N] (x,y)                 disc_sets
+    const double *hemi;   // [S][D][3][N] SoA x|y|z planes hemi_sets
+    const int32_t *rowperm;  // [H][S] sample-set index per (row, col)
+    // work: rows first_row + k*row_stride, k < num_rows
+    double *out;          // [num_rows][W][3]
+    int32_t first_row, row_stride, num_rows;
+    int32_t pad;
+    unsigned long long *stats;  // 8 counters or nullptr
+};
+
+}  // namespace flux

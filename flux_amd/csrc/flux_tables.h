@@ -1,0 +1,19 @@
+// flux_tables.h -- host entry points of tables.hip / render.hip used by abi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "flux_device.h"
+
+namespace flux {
+
+// MasterSampleSets::new (sampling.rs:13-33) + shuffle_indices for all H rows
+// (sampling.rs:35-40), generated on the device.  Synchronises `stream`.
+hipError_t generate_tables(uint64_t seed, uint32_t S, uint32_t D, uint32_t n, uint32_t H,
+                           double2 *pix, double2 *disc, double *hemi, int32_t *rowperm,
+                           hipStream_t stream);
+hipError_t hemi_to_aos(size_t SD, size_t N, const double *in, double *out, hipStream_t stream);
+
+// Camera::render (trace.rs:53-97).  variant: FLUX_KERNEL_STATIC / FLUX_KERNEL_REFILL.
+hipError_t launch_render(const RenderParams &p, int variant, hipStream_t stream);
+
+}  // namespace flux

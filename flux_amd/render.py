@@ -1,0 +1,140 @@
+"""Renderer: the Scene + Camera pair of the reference, backed by the HIP library.
+
+    Scene::from_data(job.scene_data, job.config)     fluxcore/src/workers.rs:46
+    Camera::new(..., num_sets = image_width, ...)    fluxcore/src/workers.rs:47-54
+    camera.render(&scene, unit) -> WorkUnitResult    fluxcore/src/workers.rs:60
+
+All compute happens in libflux_hip.so on the GPU; there is no CPU path here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .scene import JobConfiguration, SceneData, SceneDesc, WorkUnit, WorkUnitResult
+
+STAT_NAMES = ("samples", "segments", "matte_bounces", "glossy_bounces", "specular_bounces",
+              "emissive_hits", "misses", "depth_exhausted")
+
+
+class Renderer:
+    def __init__(self, scene_data: SceneData, config: JobConfiguration, seed: int = 1, device: int = 0):
+        self.scene_data = scene_data
+        self.config = config
+        self.seed = int(seed)
+        self.device = int(device)
+        self.width = scene_data.output_settings.image_width
+        self.height = scene_data.output_settings.image_height
+        self._desc = SceneDesc(scene_data)
+        cfg = _lib.FluxJobCfg(config.sample_root, config.max_trace_depth, config.rows_per_work_unit)
+        h = C.c_void_p()
+        _lib.check(_lib.lib.flux_ctx_create(C.byref(self._desc.desc), C.byref(cfg), C.c_uint64(self.seed),
+                                            self.device, C.byref(h)))
+        self._h = h
+
+    # -- lifetime ------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib.flux_ctx_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _handle(self):
+        if not self._h:
+            raise _lib.FluxError(_lib.E_INVALID, "renderer is closed")
+        return self._h
+
+    # -- Camera::render --------------------------------------------------------
+    def render(self, unit: WorkUnit) -> WorkUnitResult:
+        """Camera::render (trace.rs:53-97): rows [row_start,row_end] inclusive."""
+        rows = self.render_rows(unit.row_start, unit.row_end)
+        return WorkUnitResult(work_unit=unit, rows=rows)
+
+    def render_rows(self, row_start: int, row_end: int) -> np.ndarray:
+        if row_start < 0 or row_end < row_start:
+            raise _lib.FluxError(_lib.E_INVALID, f"bad row range [{row_start},{row_end}]")
+        n = row_end - row_start + 1
+        out = np.empty((n, self.width, 3), dtype=np.float64)
+        _lib.check(_lib.lib.flux_render_rows(self._handle(), row_start, row_end,
+                                             out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def render_rows_device(self, first_row: int, row_stride: int, num_rows: int, d_out_ptr: int, stream: int = 0):
+        """Asynchronous device-resident render (see flux_render_rows_device)."""
+        _lib.check(_lib.lib.flux_render_rows_device(self._handle(), first_row, row_stride, num_rows,
+                                                    C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def render_frame(self) -> np.ndarray:
+        return self.render_rows(0, self.height - 1)
+
+    # -- knobs / introspection ---------------------------------------------------
+    def set_kernel(self, variant: int):
+        _lib.check(_lib.lib.flux_ctx_set_kernel(self._handle(), variant))
+
+    def last_kernel_ms(self) -> float:
+        return float(_lib.lib.flux_ctx_last_kernel_ms(self._handle()))
+
+    def enable_stats(self, on=True):
+        _lib.check(_lib.lib.flux_ctx_enable_stats(self._handle(), 1 if on else 0))
+
+    def stats(self, reset=False) -> dict:
+        buf = (C.c_uint64 * 8)()
+        _lib.check(_lib.lib.flux_ctx_stats(self._handle(), buf, 1 if reset else 0))
+        return dict(zip(STAT_NAMES, [int(x) for x in buf]))
+
+    def table(self, which: int) -> np.ndarray:
+        S = self.width
+        N = self.config.sample_root ** 2
+        D = self.config.max_trace_depth
+        shape = (S, N, 2) if which in (_lib.TABLE_PIXEL, _lib.TABLE_DISC) else (S, D, N, 3)
+        out = np.empty(shape, dtype=np.float64)
+        _lib.check(_lib.lib.flux_ctx_copy_table(self._handle(), which, out.ctypes.data_as(C.POINTER(C.c_double)),
+                                                out.size))
+        return out
+
+    def row_perm(self, row: int) -> np.ndarray:
+        out = np.empty(self.width, dtype=np.int32)
+        _lib.check(_lib.lib.flux_ctx_copy_row_perm(self._handle(), row, out.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                   out.size))
+        return out
+
+    def camera_basis(self) -> np.ndarray:
+        out = np.empty(9, dtype=np.float64)
+        _lib.check(_lib.lib.flux_ctx_camera_basis(self._handle(), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out.reshape(3, 3)
+
+    def device_bytes(self) -> int:
+        return int(_lib.lib.flux_ctx_device_bytes(self._handle()))
+
+
+def work_units(image_height: int, rows_per_work_unit: int):
+    """Job::work_units (job.rs:65-88) through the C ABI."""
+    n = _lib.lib.flux_work_units(image_height, rows_per_work_unit, None, 0)
+    _lib.check(n)
+    buf = (_lib.FluxWorkUnit * max(n, 1))()
+    _lib.check(_lib.lib.flux_work_units(image_height, rows_per_work_unit, buf, n))
+    return [WorkUnit(int(buf[i].row_start), int(buf[i].row_end)) for i in range(n)]
+
+
+def write_ppm(path: str, rgb: np.ndarray, rows_present=None):
+    """Image::write (image.rs:43-61) through the C ABI."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+    h, w, c = rgb.shape
+    assert c == 3
+    rp = None
+    if rows_present is not None:
+        rp_arr = np.ascontiguousarray(rows_present, dtype=np.uint8)
+        assert rp_arr.shape == (h,)
+        rp = rp_arr.ctypes.data_as(C.POINTER(C.c_uint8))
+    _lib.check(_lib.lib.flux_write_ppm(path.encode(), rgb.ctypes.data_as(C.POINTER(C.c_double)), w, h, rp))

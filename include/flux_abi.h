@@ -1,0 +1,197 @@
+/*
+ * flux_abi.h -- C ABI of the MI355X (gfx950) render path for jtdaugherty/flux.
+ *
+ * This is the drop-in boundary for fluxcore's per-pixel render loop.  In the
+ * reference the path sits behind exactly three calls made by the LocalWorker
+ * job loop (fluxcore/src/workers.rs:46-60):
+ *
+ *     Scene::from_data(job.scene_data, job.config)        workers.rs:46
+ *     Camera::new(..., num_sets = image_width, ...)       workers.rs:47-54
+ *     camera.render(&scene, unit) -> WorkUnitResult       workers.rs:60
+ *
+ * A GPU worker (a third sibling of LocalWorker / NetworkWorker behind
+ * `trait Worker`, fluxcore/src/manager.rs:232-236) binds the entry points
+ * below instead; INTEGRATION.md shows the Rust `extern "C"` block.
+ *
+ * Plain pointers and sizes only; no C++/torch types.  All floating point is
+ * IEEE f64 as in the reference.  Functions return 0 on success or a negative
+ * FLUX_E_* code; flux_last_error() gives the message for the calling thread
+ * (the reference panics instead -- workers.rs:78, job.rs:67-70 -- a C ABI
+ * must not unwind).
+ */
+#ifndef FLUX_ABI_H
+#define FLUX_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLUX_ABI_VERSION 1
+
+/* error codes */
+#define FLUX_OK 0
+#define FLUX_E_INVALID (-1)  /* bad argument (null, out-of-range row, root<1, depth<1 ...) */
+#define FLUX_E_DEVICE (-2)   /* HIP runtime error / no usable gfx950 device */
+#define FLUX_E_NOMEM (-3)    /* device or host allocation failed */
+#define FLUX_E_IO (-4)       /* file output failed */
+
+/* ShapeData variants: fluxcore/src/scene.rs:71-74 */
+#define FLUX_SHAPE_SPHERE 0
+#define FLUX_SHAPE_PLANE 1
+
+/* MaterialData variants: fluxcore/src/shapes.rs:42-47 */
+#define FLUX_MAT_MATTE 0       /* MatteData            shapes.rs:52-56 */
+#define FLUX_MAT_EMISSIVE 1    /* EmissiveData         shapes.rs:61-64 */
+#define FLUX_MAT_REFLECTIVE 2  /* ReflectiveData       shapes.rs:69-72 */
+#define FLUX_MAT_GLOSSY 3      /* GlossyReflectiveData shapes.rs:77-81 */
+
+/* MaterialData (shapes.rs:42-81) flattened:
+ *   Matte     : color = diffuse_color, ambient = ambient_color (parsed but
+ *               unused by path_shade, materials.rs:18-34), k = diffuse_coefficient
+ *   Emissive  : color, k = power
+ *   Reflective: color = reflect_color, k = reflect_amount
+ *   Glossy    : color = reflect_color, k = reflect_amount, exponent = reflect_exponent */
+typedef struct flux_material {
+    int32_t kind;
+    int32_t reserved;
+    double color[3];
+    double ambient[3];
+    double k;
+    double exponent;
+} flux_material;
+
+/* ShapeData (scene.rs:71-74) = SphereData (shapes.rs:18-23) | PlaneData
+ * (shapes.rs:33-37).  sphere: p = center, radius, invert.  plane: p = point,
+ * n = normal (used as given: never normalised or flipped, shapes.rs:135-152). */
+typedef struct flux_shape {
+    int32_t kind;
+    int32_t invert;
+    double p[3];
+    double n[3];
+    double radius;
+    flux_material material;
+} flux_shape;
+
+/* SceneData (scene.rs:40-49) with CameraSettings (:14-18), CameraData
+ * (:53-58) and OutputSettings (:62-66) inlined.  `shapes` keeps YAML order:
+ * Scene::hit resolves distance ties to the lowest index (scene.rs:156-160,
+ * common.rs:17-23). */
+typedef struct flux_scene_desc {
+    const char *scene_name;
+    uint64_t image_width;
+    uint64_t image_height;
+    double pixel_size;
+    double background[3];
+    double eye[3];
+    double look_at[3];
+    double up[3];
+    double zoom_factor;
+    double view_plane_distance;
+    double focal_distance;
+    double lens_radius;
+    uint64_t num_shapes;
+    const flux_shape *shapes;
+} flux_scene_desc;
+
+/* JobConfiguration: fluxcore/src/job.rs:49-53 */
+typedef struct flux_job_cfg {
+    uint64_t sample_root;
+    uint64_t max_trace_depth;
+    uint64_t rows_per_work_unit;
+} flux_job_cfg;
+
+/* WorkUnit: fluxcore/src/job.rs:40-44 (row_end inclusive; job_id is
+ * scheduler bookkeeping and stays on the caller's side) */
+typedef struct flux_work_unit {
+    uint64_t row_start;
+    uint64_t row_end;
+} flux_work_unit;
+
+typedef struct flux_ctx flux_ctx;
+
+uint32_t flux_abi_version(void);
+const char *flux_last_error(void);
+
+/* Number of usable devices (0 when no GPU is visible; never fails). */
+int flux_device_count(void);
+
+/* Replaces Scene::from_data (scene.rs:128-154) + Camera::new (trace.rs:26-42)
+ * incl. MasterSampleSets::new (sampling.rs:13-33): copies the scene, uploads
+ * it to HBM and generates the S = image_width sample sets of pixel / lens-disc
+ * / hemisphere tables ON THE DEVICE.  `seed` is an addition: the reference
+ * seeds from OS entropy (samplers/src/lib.rs:27-33); see DESIGN.md "RNG
+ * contract".  The caller keeps ownership of `scene`. */
+int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint64_t seed,
+                    int device, flux_ctx **out);
+
+/* Drops Scene + Camera (workers.rs:73-74). NULL is a no-op. */
+void flux_ctx_destroy(flux_ctx *ctx);
+
+/* Replaces Camera::render (trace.rs:53-97) for one WorkUnit.  Writes
+ * (row_end-row_start+1) * image_width * 3 doubles, row-major RGB, already
+ * averaged over sample_root^2 samples and max_to_one-clamped -- exactly what
+ * WorkUnitResult.rows holds (manager.rs:24-28).  Synchronous: returns after
+ * the device->host copy.  out_rgb is caller-owned host memory. */
+int flux_render_rows(flux_ctx *ctx, uint64_t row_start, uint64_t row_end, double *out_rgb);
+
+/* Same render, device-resident: rows first_row, first_row+row_stride, ...
+ * (num_rows of them) are written to d_out_rgb (device pointer, num_rows *
+ * image_width * 3 doubles) asynchronously on `hip_stream` (a hipStream_t, or
+ * NULL for the default stream).  This is what the multi-GPU path uses so that
+ * the framebuffer gather (RCCL) never leaves HBM.  row_stride >= 1. */
+int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stride,
+                            uint64_t num_rows, void *d_out_rgb, void *hip_stream);
+
+/* Render-kernel variants (all produce the same image within rounding):
+ *   0 = default (currently FLUX_KERNEL_REFILL)
+ *   1 = FLUX_KERNEL_STATIC: one lane per sample, lanes idle once their path ends
+ *   2 = FLUX_KERNEL_REFILL: persistent lanes refilled with the pixel's next
+ *       sample by ballot/prefix compaction */
+#define FLUX_KERNEL_DEFAULT 0
+#define FLUX_KERNEL_STATIC 1
+#define FLUX_KERNEL_REFILL 2
+int flux_ctx_set_kernel(flux_ctx *ctx, int variant);
+
+/* Device time (ms, HIP events on the launch stream) of the most recent render
+ * kernel launched through this context; synchronises that launch. <0 on error. */
+double flux_ctx_last_kernel_ms(flux_ctx *ctx);
+
+/* Path statistics of the launches since the last reset (requires
+ * flux_ctx_enable_stats(ctx,1) before rendering; off by default):
+ * [0] samples, [1] ray segments, [2] Matte bounces, [3] glossy bounces,
+ * [4] perfect-specular bounces, [5] emissive terminations, [6] misses,
+ * [7] depth-exhausted paths. */
+int flux_ctx_enable_stats(flux_ctx *ctx, int on);
+int flux_ctx_stats(flux_ctx *ctx, uint64_t out[8], int reset);
+
+/* Introspection used by the parity tests (device -> host copies).
+ * which: 0 = pixel_sets [S][N][2], 1 = disc_sets [S][N][2],
+ *        2 = hemi_sets  [S][D][N][3] (converted from the device SoA layout). */
+#define FLUX_TABLE_PIXEL 0
+#define FLUX_TABLE_DISC 1
+#define FLUX_TABLE_HEMI 2
+int flux_ctx_copy_table(flux_ctx *ctx, int which, double *out, uint64_t out_doubles);
+int flux_ctx_copy_row_perm(flux_ctx *ctx, uint64_t row, int32_t *out, uint64_t out_len);
+int flux_ctx_camera_basis(flux_ctx *ctx, double uvw[9]); /* CameraBasis::new scene.rs:28-35 */
+/* bytes of HBM held by the context's tables + scene */
+uint64_t flux_ctx_device_bytes(flux_ctx *ctx);
+
+/* Job::work_units (job.rs:65-88), including its `i < H-1` loop guard.  Writes
+ * at most `cap` units and returns the number the reference would issue, or a
+ * negative code (rows_per_work_unit == 0 panics in the reference). */
+int64_t flux_work_units(uint64_t image_height, uint64_t rows_per_work_unit, flux_work_unit *out,
+                        uint64_t cap);
+
+/* Image::write (image.rs:43-61): ASCII P3, maxval 65535, `(c*65535.99) as
+ * u16`, one pixel per line; rows whose rows_present[r]==0 (never received) are
+ * written as zeros.  rows_present may be NULL (all present). */
+int flux_write_ppm(const char *path, const double *rgb, uint64_t width, uint64_t height,
+                   const uint8_t *rows_present);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUX_ABI_H */

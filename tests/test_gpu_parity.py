@@ -1,0 +1,157 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerance: BASELINE.json's north_star states 1e-4 per channel at a fixed seed.  Both sides are FP64
+with the reference's operation order, so the observed difference is ~1e-13 (libm vs OCML sin/cos/pow
+differ by ulps); the tests assert 1e-9 where no ray/primitive decision can flip and 1e-4 (the stated
+tolerance) on whole images.
+"""
+import numpy as np
+import pytest
+
+from conftest import max_abs_diff, small_scene
+
+pytestmark = pytest.mark.gpu
+
+TOL_IMAGE = 1e-4   # north_star tolerance (per channel)
+TOL_TIGHT = 1e-9   # what FP64 + same operation order actually delivers
+
+
+def _pair(flux, oracle_mod, sd, n, D=5, seed=1):
+    cfg = flux.JobConfiguration(n, D, 50)
+    return flux.Renderer(sd, cfg, seed=seed), oracle_mod.Oracle(sd, cfg, seed=seed)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
+def test_tables_match_oracle(flux, oracle_mod, demo2, n):
+    sd = small_scene(demo2, 40, 30)
+    r, o = _pair(flux, oracle_mod, sd, n, D=3)
+    # square samples are pure IEEE +,/ on the same draws: bit-exact
+    assert np.array_equal(r.table(flux._lib.TABLE_PIXEL), o.pixel_sets())
+    # disc / hemisphere go through sin, cos, pow: ulp-level libm differences only
+    assert max_abs_diff(r.table(flux._lib.TABLE_DISC), o.disc_sets()) < 1e-14
+    assert max_abs_diff(r.table(flux._lib.TABLE_HEMI), o.hemi_sets()) < 1e-14
+    for row in (0, 7, 29):
+        assert np.array_equal(r.row_perm(row), o.row_perm(row))
+    assert max_abs_diff(r.camera_basis(), o.camera_basis()) == 0.0
+    r.close()
+
+
+@pytest.mark.parametrize("scene_name", ["demo1", "demo2"])
+@pytest.mark.parametrize("n", [1, 3, 4, 8, 9])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_image_parity_small(flux, oracle_mod, demo1, demo2, scene_name, n, variant):
+    sd = small_scene(demo1 if scene_name == "demo1" else demo2, 64, 48)
+    r, o = _pair(flux, oracle_mod, sd, n)
+    r.set_kernel(variant)
+    got = r.render_frame()
+    want = o.render_frame(threads=8)
+    assert got.shape == want.shape == (48, 64, 3)
+    d = max_abs_diff(got, want)
+    assert d < TOL_IMAGE, d
+    # report-quality check: typically ~1e-13
+    assert np.percentile(np.abs(got - want), 99.9) < TOL_TIGHT
+    r.close()
+
+
+def test_full_width_rows_parity(flux, oracle_mod, demo2):
+    """Full 800-wide rows of the real demo2 scene (config 3 geometry) at 64 spp."""
+    r, o = _pair(flux, oracle_mod, demo2, 8)
+    for (a, b) in [(0, 1), (298, 301), (598, 599)]:
+        got = r.render_rows(a, b)
+        want = o.render_rows(a, b, threads=8)
+        assert max_abs_diff(got, want) < TOL_IMAGE
+    r.close()
+
+
+def test_stats_match_oracle(flux, oracle_mod, demo2):
+    sd = small_scene(demo2, 64, 48)
+    r, o = _pair(flux, oracle_mod, sd, 8)
+    for variant in (1, 2):
+        r.set_kernel(variant)
+        r.enable_stats(True)
+        r.stats(reset=True)
+        r.render_frame()
+        o.stats(reset=True)
+        o.render_frame(threads=4)
+        assert r.stats() == o.stats()
+    r.close()
+
+
+def test_work_unit_sharding_invariance(flux, demo2):
+    """Rendering the frame as reference work units, single rows or strided rows gives the same pixels
+    bit for bit (the per-row permutation is keyed by (seed,row), not by the launch)."""
+    sd = small_scene(demo2, 64, 48)
+    r = flux.Renderer(sd, flux.JobConfiguration(8, 5, 50), seed=7)
+    full = r.render_frame()
+    units = flux.work_units(48, 10)
+    parts = np.concatenate([r.render(u).rows for u in units], axis=0)
+    assert np.array_equal(parts, full[: parts.shape[0]])
+    single = np.concatenate([r.render_rows(k, k) for k in range(48)], axis=0)
+    assert np.array_equal(single, full)
+    again = r.render_frame()
+    assert np.array_equal(again, full)  # run-to-run determinism (no atomics)
+    r.close()
+
+
+def test_seed_changes_image(flux, demo2):
+    sd = small_scene(demo2, 32, 24)
+    a = flux.Renderer(sd, flux.JobConfiguration(4, 5, 50), seed=1).render_frame()
+    b = flux.Renderer(sd, flux.JobConfiguration(4, 5, 50), seed=2).render_frame()
+    assert not np.array_equal(a, b)
+    assert abs(a.mean() - b.mean()) < 0.05
+
+
+@pytest.mark.parametrize("D", [1, 2, 7])
+def test_depth_limits(flux, oracle_mod, demo1, D):
+    sd = small_scene(demo1, 32, 24)
+    r, o = _pair(flux, oracle_mod, sd, 4, D=D)
+    assert max_abs_diff(r.render_frame(), o.render_frame(threads=4)) < TOL_IMAGE
+    r.close()
+
+
+def test_empty_scene_and_background(flux, oracle_mod, demo1):
+    import copy
+    sd = small_scene(demo1, 16, 8)
+    sd = copy.deepcopy(sd)
+    sd.shapes = []
+    sd.background = (0.25, 0.5, 2.0)  # exercises max_to_one on the background path
+    r, o = _pair(flux, oracle_mod, sd, 2)
+    got = r.render_frame()
+    assert max_abs_diff(got, o.render_frame()) == 0.0
+    assert np.allclose(got, np.array([0.125, 0.25, 1.0]))
+    r.close()
+
+
+def test_reflective_and_tie_break(flux, oracle_mod, demo1):
+    """PerfectSpecular (unused by the demos but part of the schema) and coincident shapes
+    (lowest YAML index wins, scene.rs:156-160)."""
+    import copy
+    sd = copy.deepcopy(small_scene(demo1, 48, 36))
+    s = sd.shapes
+    s[2].material = flux.ReflectiveData(0.8, (0.9, 0.9, 1.0))
+    twin = copy.deepcopy(s[1])
+    twin.material = flux.EmissiveData((1.0, 0.0, 0.0), 5.0)
+    s.insert(2, twin)  # same centre/radius as shape 1, later in order: must never be seen
+    r, o = _pair(flux, oracle_mod, sd, 4)
+    got, want = r.render_frame(), o.render_frame(threads=4)
+    assert max_abs_diff(got, want) < TOL_IMAGE
+    r.close()
+
+
+def test_abi_errors(flux, demo1):
+    sd = small_scene(demo1, 16, 8)
+    with pytest.raises(flux.FluxError):
+        flux.Renderer(sd, flux.JobConfiguration(0, 5, 50))
+    with pytest.raises(flux.FluxError):
+        flux.Renderer(sd, flux.JobConfiguration(2, 0, 50))
+    with pytest.raises(flux.FluxError):
+        flux.Renderer(sd, flux.JobConfiguration(2, 5, 50), device=99)
+    r = flux.Renderer(sd, flux.JobConfiguration(2, 5, 50))
+    with pytest.raises(flux.FluxError):
+        r.render_rows(0, 8)      # row_end == H is out of range
+    with pytest.raises(flux.FluxError):
+        r.render_rows(5, 4)
+    assert r.render_rows(7, 7).shape == (1, 16, 3)
+    r.close()
+    with pytest.raises(flux.FluxError):
+        r.render_rows(0, 0)      # closed
