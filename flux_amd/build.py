@@ -1,10 +1,7 @@
-"""Build the in-tree native libraries.
+"""Build the in-tree native library ``flux_amd/libflux_hip.so``: HIP kernels + the C ABI of
+include/flux_abi.h, cross-compiled for gfx950 with hipcc (works without a GPU).
 
-* ``flux_amd/libflux_hip.so`` -- the product: HIP kernels + C ABI (include/flux_abi.h),
-  cross-compiled for gfx950 with hipcc (works without a GPU).
-* ``oracle/libflux_oracle.so`` -- the CPU oracle (test infrastructure only), gcc.
-
-The ``.so`` files are git-ignored but travel with the gpurun snapshot.
+The ``.so`` is git-ignored but travels with the gpurun snapshot.
 """
 import os
 import shutil
@@ -16,8 +13,6 @@ CSRC = os.path.join(ROOT, "flux_amd", "csrc")
 HIP_SOURCES = ["abi.hip", "tables.hip", "render.hip"]
 HIP_HEADERS = ["flux_device.h", "flux_rng.h", "flux_tables.h"]
 HIP_LIB = os.path.join(ROOT, "flux_amd", "libflux_hip.so")
-ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "libflux_oracle.so")
 
 # -ffp-contract=off: the kernels keep the reference's operation order and never
 # fuse a*b+c (rustc does not contract); see DESIGN.md "Numerics".
@@ -51,18 +46,5 @@ def build_hip(force=False, verbose=False):
     return HIP_LIB
 
 
-def build_oracle(force=False, verbose=False):
-    deps = [os.path.join(ORACLE_DIR, f) for f in ("flux_oracle.c", "flux_oracle.h", "Makefile")]
-    if not force and not _newer(ORACLE_LIB, deps):
-        return ORACLE_LIB
-    subprocess.run(["make", "-C", ORACLE_DIR] + (["-B"] if force else []), check=True,
-                   stdout=None if verbose else subprocess.DEVNULL)
-    return ORACLE_LIB
-
-
-def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_oracle(force, verbose)
-
-
 if __name__ == "__main__":
-    print(build_all(force="--force" in sys.argv, verbose=True))
+    print(build_hip(force="--force" in sys.argv, verbose=True))

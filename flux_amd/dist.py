@@ -1,0 +1,71 @@
+"""Multi-GPU frame rendering: image rows shard across ranks, one framebuffer gather.
+
+In the reference the same two steps are the shared work-unit channel handed to every worker
+(fluxcore/src/manager.rs:100,156-162) and ImageBuilder placing RowsReady rows by row_start
+(manager.rs:316-324).  Here the partition is static -- rank r renders rows r, r+G, r+2G, ... so cheap
+sky rows and expensive sphere rows are spread evenly -- and the reassembly is ONE collective
+(all_gather over RCCL/xGMI on GPUs, gloo on CPU for tests) followed by a stride-interleave view.
+Pixels are independent given (seed, row), so the assembled image is bit-identical for every G.
+
+torch is plumbing here (device buffers, streams, the process group); the pixels come from the
+`render_fn` callable (Renderer.render_rows_device via hip_render_fn below; the gloo tests inject
+their own CPU checker).
+"""
+from typing import Callable, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def rank_rows(height: int, rank: int, world: int) -> Tuple[int, int, int]:
+    """(first_row, row_stride, num_rows) of `rank`'s share of an image of `height` rows."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    count = (height - rank + world - 1) // world if height > rank else 0
+    return rank, world, count
+
+
+def rows_per_rank(height: int, world: int) -> int:
+    """Padded per-rank row count (rank 0 always has the most rows)."""
+    return (height + world - 1) // world
+
+
+class FrameSharder:
+    """Owns the per-rank row buffer and the gathered frame for one image geometry."""
+
+    def __init__(self, height: int, width: int, rank: int, world: int, device, group=None):
+        self.height, self.width, self.rank, self.world = height, width, rank, world
+        self.group = group
+        self.first, self.stride, self.count = rank_rows(height, rank, world)
+        self.rmax = rows_per_rank(height, world)
+        # zero-initialised: padded rows (ranks with one row fewer) stay zero, like Image::write's
+        # zero padding of never-received rows (image.rs:55-59)
+        self.local = torch.zeros((self.rmax, width, 3), dtype=torch.float64, device=device)
+        self.gathered = torch.zeros((world, self.rmax, width, 3), dtype=torch.float64, device=device)
+
+    def render(self, render_fn: Callable[[int, int, int, torch.Tensor], None]):
+        """render_fn(first_row, row_stride, num_rows, out) fills out[:num_rows] ([rows][W][3] f64)."""
+        if self.count:
+            render_fn(self.first, self.stride, self.count, self.local)
+
+    def gather(self) -> torch.Tensor:
+        """One collective; returns the assembled [H][W][3] frame (a view, valid on every rank)."""
+        if self.world == 1:
+            return self.local[: self.height]
+        dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
+        # gathered[g][k] is image row k*G + g  ->  [k][g] order is image order
+        return self.gathered.permute(1, 0, 2, 3).reshape(self.rmax * self.world, self.width, 3)[: self.height]
+
+    def step(self, render_fn) -> torch.Tensor:
+        self.render(render_fn)
+        return self.gather()
+
+
+def hip_render_fn(renderer):
+    """render_fn backed by the HIP library, launched on torch's current stream."""
+
+    def fn(first, stride, count, out):
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        renderer.render_rows_device(first, stride, count, out.data_ptr(), stream)
+
+    return fn

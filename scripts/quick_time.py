@@ -1,0 +1,27 @@
+"""Quick kernel timing on the GPU box (development aid, not the bench contract)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import flux_amd
+
+scene = sys.argv[1] if len(sys.argv) > 1 else "demo2"
+roots = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["8", "32"])]
+variants = [int(x) for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["1", "2"])]
+sd = flux_amd.load_scene(f"scenes/{scene}.yml")
+W, H = sd.output_settings.image_width, sd.output_settings.image_height
+for n in roots:
+    t = time.time()
+    r = flux_amd.Renderer(sd, flux_amd.JobConfiguration(n, 5, 50), seed=1)
+    t_create = time.time() - t
+    print(f"{scene} n={n} spp={n*n}: ctx_create {t_create*1e3:.1f} ms, HBM {r.device_bytes()/1e6:.1f} MB", flush=True)
+    for v in variants:
+        r.set_kernel(v)
+        best = 1e30
+        for rep in range(3):
+            t = time.time()
+            img = r.render_frame()
+            wall = time.time() - t
+            ms = r.last_kernel_ms()
+            best = min(best, ms)
+            print(f"   variant {v} rep {rep}: kernel {ms:.2f} ms  wall {wall*1e3:.1f} ms  {W*H*n*n/ms/1e3:.1f} Msamples/s  mean={img.mean():.6f}", flush=True)
+    r.close()

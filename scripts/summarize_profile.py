@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ rocprofv3 run (scripts/profile_gpu.sh) into profiles/:
+  profiles/<tag>_kernel_stats.csv   -- rocprofv3 --kernel-trace --stats summary, verbatim
+  profiles/<tag>_pmc.json           -- per-launch counters of the render kernel + the bench lines
+Usage: scripts/summarize_profile.py <tag> [fetch_scale]
+fetch_scale: factor applied to FETCH_SIZE for the HBM-bytes figure (see DESIGN.md "Traffic counters").
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+
+counters = collections.defaultdict(lambda: collections.defaultdict(list))
+meta = collections.defaultdict(dict)
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            name = row["Kernel_Name"]
+            if "render_" not in name:
+                continue
+            counters[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            for k in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Workgroup_Size", "Grid_Size"):
+                meta[name][k] = float(row[k])
+
+bench = {}
+for f in glob.glob(os.path.join(src, "bench_*.json")):
+    try:
+        bench[os.path.basename(f)[:-5]] = json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception:
+        pass
+
+out = {"tag": tag, "kernels": {}, "bench_lines": bench}
+workload = None
+for b in bench.values():
+    workload = b.get("config", {}).get("workload", workload)
+out["workload"] = workload
+main = None
+for name, cs in counters.items():
+    k = {c: sum(v) / len(v) for c, v in cs.items()}
+    k.update(meta[name])
+    out["kernels"][name] = k
+    if "<false>" in name or main is None:
+        main = k
+if main and "FETCH_SIZE" in main and "WRITE_SIZE" in main:
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in units of 1024 B
+    out["hbm_bytes_per_launch_raw"] = (main["FETCH_SIZE"] + main["WRITE_SIZE"]) * 1024.0
+    scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+    out["fetch_scale"] = scale
+    out["hbm_bytes_per_launch"] = (main["FETCH_SIZE"] * scale + main["WRITE_SIZE"]) * 1024.0
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "bench_lines"}, indent=1)[:3000])

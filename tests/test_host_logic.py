@@ -1,0 +1,54 @@
+"""Host-side pieces of the boundary that need no GPU: Job::work_units and Image::write through the
+C ABI, checked against the oracle's restatement."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("h,r", [(600, 50), (600, 1), (601, 50), (600, 1000), (2, 1), (1, 50), (7, 3), (600, 599)])
+def test_work_units_match_oracle(flux, oracle_mod, h, r):
+    got = [(u.row_start, u.row_end) for u in flux.work_units(h, r)]
+    assert got == oracle_mod.work_units(h, r)
+
+
+def test_work_units_zero_rows_is_an_error(flux):
+    with pytest.raises(flux.FluxError):   # job.rs:67-70 panics
+        flux.work_units(600, 0)
+
+
+def test_work_units_cover_rows_in_order(flux):
+    us = flux.work_units(600, 50)
+    assert len(us) == 12
+    rows = [r for u in us for r in range(u.row_start, u.row_end + 1)]
+    assert rows == list(range(600))
+    assert len(flux.work_units(600, 1)) == 599  # the reference never issues the last single row
+
+
+def test_write_ppm_matches_oracle(flux, oracle_mod, tmp_path):
+    rng = np.random.default_rng(3)
+    img = rng.random((9, 7, 3)) * 1.2 - 0.1   # includes <0 and >1 values
+    img[0, 0] = [1.0, 0.5, 0.0]
+    img[1, 1] = [np.nan, np.inf, -np.inf]
+    present = np.array([1, 1, 0, 1, 1, 1, 0, 1, 1], dtype=np.uint8)
+    a, b = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")
+    flux.write_ppm(a, img, present)
+    oracle_mod.write_ppm(b, img, present)
+    ta, tb = open(a).read(), open(b).read()
+    assert ta == tb
+    lines = ta.splitlines()
+    assert lines[:4] == ["P3", "7 9", "65535", "65535 32767 0"] and len(lines) == 3 + 63
+    flux.write_ppm(a, img)
+    oracle_mod.write_ppm(b, img)
+    assert open(a).read() == open(b).read()
+
+
+def test_write_ppm_io_error(flux):
+    with pytest.raises(flux.FluxError):
+        flux.write_ppm("/nonexistent_dir/x.ppm", np.zeros((1, 1, 3)))
+
+
+def test_no_gpu_means_loud_failure(flux, demo1):
+    """On a box without a GPU the product refuses to render (no CPU fallback)."""
+    if flux._lib.lib.flux_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(flux.FluxError, match="no HIP device"):
+        flux.Renderer(demo1, flux.JobConfiguration(1, 5, 50))

@@ -1,0 +1,428 @@
+"""Known-answer and property tests that pin the CPU oracle.
+
+The reference has no tests or golden vectors and a non-reproducible RNG, so every
+expected value below is hand-derived from the reference's formulae (file:line cited per test), not
+produced by running reference code.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, small_scene
+
+M64 = (1 << 64) - 1
+GOLDEN_GAMMA = 0x9E3779B97F4A7C15
+
+
+def mix64(z):
+    z &= M64
+    z ^= z >> 30
+    z = (z * 0xBF58476D1CE4E5B9) & M64
+    z ^= z >> 27
+    z = (z * 0x94D049BB133111EB) & M64
+    z ^= z >> 31
+    return z
+
+
+# ---------------------------------------------------------------- RNG contract
+def test_rng_is_splitmix64(oracle_mod):
+    O = oracle_mod
+    # published splitmix64 test vector for seed 0
+    want = [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F, 0xF88BB8A8724C81EC]
+    assert [O.lib.fxo_rng_draw(0, c) for c in range(4)] == want
+    for key in (1, 0xDEADBEEF, M64):
+        for c in (0, 1, 77, 1 << 40):
+            assert O.lib.fxo_rng_draw(key, c) == mix64(key + (c + 1) * GOLDEN_GAMMA)
+    u = O.lib.fxo_rng_unit(0, 0)
+    assert u == (0xE220A8397B1DCDAF >> 11) / 2.0 ** 53 and 0.0 <= u < 1.0
+
+
+def test_rng_key_folding(oracle_mod):
+    def fold(k, v):
+        return mix64((k ^ v) + GOLDEN_GAMMA)
+    seed, kind, a, b, sub = 12345, 3, 17, 4, 9
+    k = fold(fold(fold(fold(mix64(seed + GOLDEN_GAMMA), kind), a), b), sub)
+    assert oracle_mod.lib.fxo_rng_key(seed, kind, a, b, sub) == k
+
+
+def test_shuffle_matches_rand_0_5_loop(oracle_mod):
+    """rand 0.5.5 Rng::shuffle: i = len-1..1, swap(v[i], v[gen_range(0, i+1)]) -- python restatement."""
+    O = oracle_mod
+    key = 0xABCDEF
+    for n in (1, 2, 5, 33, 800):
+        ctr = [0]
+
+        def below(bound):
+            while True:
+                x = mix64(key + (ctr[0] + 1) * GOLDEN_GAMMA)
+                ctr[0] += 1
+                m = x * bound
+                lo = m & M64
+                if lo >= bound or lo >= ((1 << 64) - bound) % bound:
+                    return m >> 64
+
+        v = list(range(n))
+        i = n
+        while i >= 2:
+            i -= 1
+            j = below(i + 1)
+            v[i], v[j] = v[j], v[i]
+        assert list(O.shuffle(key, n)) == v
+        assert sorted(v) == list(range(n))
+
+
+def test_shuffle_is_roughly_uniform(oracle_mod):
+    n, trials = 5, 6000
+    counts = np.zeros((n, n))
+    for t in range(trials):
+        p = oracle_mod.shuffle(oracle_mod.lib.fxo_rng_key(1, 4, t, 0, 0), n)
+        counts[np.arange(n), p] += 1
+    assert np.all(np.abs(counts / trials - 1.0 / n) < 0.03)
+
+
+# ------------------------------------------------------------------- samplers
+def _assert_n_rooks(pts, n, coarse_cells=True):
+    """samplers/src/lib.rs:46-90: one point per 1/n^2 strip in x and in y (n-rooks).  The correlated
+    variant also keeps one point per coarse n x n cell: sample (i,k) lands in cell
+    (x_idxs[i], y_idxs[k]), a bijection.  The plain variant as written in the reference does NOT
+    (cell (px_k[i], py_i[k]) with independent permutations can collide) -- a quirk the oracle keeps."""
+    N = n * n
+    assert pts.shape == (N, 2)
+    assert np.all(pts >= 0.0) and np.all(pts < 1.0)
+    if coarse_cells:
+        cells = (np.floor(pts[:, 0] * n).astype(int) * n + np.floor(pts[:, 1] * n).astype(int))
+        assert sorted(cells) == list(range(N))
+    for ax in (0, 1):
+        assert sorted(np.floor(pts[:, ax] * N).astype(int)) == list(range(N))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 16])
+def test_multi_jittered_stratification(oracle_mod, n):
+    O = oracle_mod
+    _assert_n_rooks(O.grid_multi_jittered(5, O.KIND_HEMI, 3, 1, n), n, coarse_cells=False)
+    _assert_n_rooks(O.grid_correlated_multi_jittered(5, O.KIND_PIXEL, 3, 0, n), n)
+
+
+def test_multi_jittered_index_layout(oracle_mod):
+    """Flat index i*n+j keeps the coarse cell of base[i][j] in x only through the x-shuffle:
+    final[i][k] = (base[px_k[i]][k].x, base[i][py_i[k]].y)  (lib.rs:64-126 composed).  Hence the fine
+    x-strip of sample (i,k) is (n-1-k) within its coarse column and the fine y-strip is (n-1-i)."""
+    O = oracle_mod
+    n = 6
+    for pts in (O.grid_multi_jittered(9, O.KIND_HEMI, 0, 0, n),
+                O.grid_correlated_multi_jittered(9, O.KIND_DISC, 0, 0, n)):
+        p = pts.reshape(n, n, 2)
+        for i in range(n):
+            for k in range(n):
+                fx = int(math.floor(p[i, k, 0] * n * n)) % n
+                fy = int(math.floor(p[i, k, 1] * n * n)) % n
+                assert fx == n - 1 - k and fy == n - 1 - i
+
+
+def test_correlated_variant_shares_permutations(oracle_mod):
+    """lib.rs:75-90: one x_idxs / y_idxs for all rows/columns -> the coarse x cell depends on i only
+    and the coarse y cell on k only; the plain MJ variant (lib.rs:64-73) does not have this."""
+    O = oracle_mod
+    n = 8
+    c = O.grid_correlated_multi_jittered(3, O.KIND_PIXEL, 1, 0, n).reshape(n, n, 2)
+    cx = np.floor(c[:, :, 0] * n).astype(int)
+    cy = np.floor(c[:, :, 1] * n).astype(int)
+    assert np.all(cx == cx[:, :1]) and np.all(cy == cy[:1, :])
+    m = O.grid_multi_jittered(3, O.KIND_HEMI, 1, 0, n).reshape(n, n, 2)
+    mx = np.floor(m[:, :, 0] * n).astype(int)
+    assert not np.all(mx == mx[:, :1])
+
+
+def test_grid_regular_and_jittered(oracle_mod):
+    O = oracle_mod
+    g = O.grid_regular(4)  # lib.rs:184-191: start 0.125, step 0.25, x outer
+    assert np.allclose(g[:5], [[0.125, 0.125], [0.125, 0.375], [0.125, 0.625], [0.125, 0.875], [0.375, 0.125]])
+    j = O.grid_jittered(77, 4)  # lib.rs:35-44: regular +- half a cell
+    assert np.all(np.abs(j - g) <= 0.125)
+
+
+def test_to_unit_hemi_kat(oracle_mod):
+    O = oracle_mod
+    h = O.to_unit_hemi(0.25, 0.5, 0.0)  # lib.rs:133-142: phi = pi/2, cos_theta = 0.5
+    assert abs(h[0]) < 1e-16 and h[1] == pytest.approx(math.sqrt(0.75), abs=1e-15) and h[2] == pytest.approx(0.5, abs=1e-15)
+    for e in (0.0, 10.0, 1e5):
+        assert np.allclose(O.to_unit_hemi(0.3, 0.0, e), [0, 0, 1], atol=1e-15)  # y = 0 -> cos_theta = 1
+    # e = 1: cos_theta = sqrt(1 - y)
+    h = O.to_unit_hemi(0.0, 0.75, 1.0)
+    assert np.allclose(h, [math.sqrt(0.75), 0.0, 0.5], atol=1e-15)
+    rng = np.random.default_rng(0)
+    for x, y in rng.random((50, 2)):
+        for e in (0.0, 10.0, 100.0):
+            v = O.to_unit_hemi(x, y, e)
+            assert abs(np.linalg.norm(v) - 1) < 1e-14 and v[2] > 0
+
+
+def test_to_poisson_disc_kat(oracle_mod):
+    O = oracle_mod  # lib.rs:144-182
+    assert np.allclose(O.to_poisson_disc(0.75, 0.5), [0.5, 0.0], atol=1e-16)
+    assert np.all(O.to_poisson_disc(0.5, 0.5) == 0.0)           # spy == 0 branch
+    d = O.to_poisson_disc(0.5, 0.75)                            # r = 0.5, phi = 2*pi/4
+    assert abs(d[0]) < 1e-16 and d[1] == pytest.approx(0.5, abs=1e-16)
+    d = O.to_poisson_disc(0.25, 0.5)                            # sector 3: r = 0.5, phi = 4*pi/4
+    assert np.allclose(d, [-0.5, 0.0], atol=1e-16)
+    d = O.to_poisson_disc(0.5, 0.25)                            # sector 4: r = 0.5, phi = 6*pi/4
+    assert np.allclose(d, [0.0, -0.5], atol=1e-16)
+    rng = np.random.default_rng(1)
+    for x, y in rng.random((200, 2)):
+        assert np.linalg.norm(O.to_poisson_disc(x, y)) <= 1.0 + 1e-15
+
+
+def test_sample_tables_properties(oracle_mod, flux, demo2):
+    """MasterSampleSets::new (sampling.rs:13-33): S sets, shapes, ranges; sets differ."""
+    sd = small_scene(demo2, 12, 9)
+    o = oracle_mod.Oracle(sd, flux.JobConfiguration(5, 3, 50), seed=4)
+    pix, disc, hemi = o.pixel_sets(), o.disc_sets(), o.hemi_sets()
+    assert pix.shape == (12, 25, 2) and disc.shape == (12, 25, 2) and hemi.shape == (12, 3, 25, 3)
+    for s in range(12):
+        _assert_n_rooks(pix[s], 5)
+    assert np.all(np.linalg.norm(disc, axis=-1) <= 1 + 1e-15)
+    assert np.allclose(np.linalg.norm(hemi, axis=-1), 1.0, atol=1e-14) and np.all(hemi[..., 2] > 0)
+    assert not np.array_equal(pix[0], pix[1]) and not np.array_equal(hemi[0, 0], hemi[0, 1])
+    # e = 0.0 (sampling.rs:25-27) gives cos_theta = (1-y)^(1/1) = 1-y: UNIFORM in cos_theta, E[z] = 1/2
+    # (a cosine-weighted map would need e = 1, E[z] = 2/3) -- the reference's choice, kept.
+    assert abs(hemi[..., 2].mean() - 0.5) < 0.01
+    p0, p1 = o.row_perm(0), o.row_perm(1)
+    assert sorted(p0) == list(range(12)) and not np.array_equal(p0, p1)
+    assert np.array_equal(p0, o.row_perm(0))  # keyed by (seed,row): reproducible
+
+
+# ------------------------------------------------------------ camera / shapes
+def test_camera_basis_kat(oracle_mod, flux, demo1, demo2):
+    cfg = flux.JobConfiguration(1, 5, 50)
+    b1 = oracle_mod.Oracle(small_scene(demo1, 8, 6), cfg).camera_basis()  # scene.rs:28-35
+    assert np.allclose(b1[2], [0, 0.0554700196225229, -0.9984603532054125], atol=1e-15)
+    assert np.allclose(b1[0], [-1, 0, 0], atol=1e-15)
+    assert np.allclose(b1[1], [0, 0.9984603532054125, 0.0554700196225229], atol=1e-15)
+    b2 = oracle_mod.Oracle(small_scene(demo2, 8, 6), cfg).camera_basis()
+    assert np.allclose(b2[2], [0, 0.4472135954999579, -0.8944271909999159], atol=1e-15)
+    assert np.allclose(b2[0], [-1, 0, 0], atol=1e-15)
+
+
+def test_centre_ray_demo2(oracle_mod, flux, demo2):
+    """ray_direction(0,0,0,0) = -W (trace.rs:44-51); from the eye it meets shape #4 (sphere at
+    (0,1,0)) at t = |eye - look_at| - 1 = 10.0623058987 - 1."""
+    o = oracle_mod.Oracle(small_scene(demo2, 8, 6), flux.JobConfiguration(1, 5, 50))
+    w = o.camera_basis()[2]
+    idx, t, n, p = o.scene_hit((0, 5.5, -9.0), tuple(-w))
+    assert idx == 4
+    assert t == pytest.approx(math.sqrt(4.5 ** 2 + 81) - 1.0, abs=1e-12)
+    assert np.allclose(n, w, atol=1e-12) and np.allclose(p, np.array([0, 1, 0]) + w, atol=1e-12)
+
+
+def test_sphere_hit_kat(oracle_mod):
+    O = oracle_mod  # shapes.rs:171-217
+    t, n, p = O.sphere_hit((0, 0, 0), 1.0, False, (0, 0, -5), (0, 0, 1))
+    assert t == 4.0 and np.array_equal(n, [0, 0, -1]) and np.array_equal(p, [0, 0, -1])
+    t, n, p = O.sphere_hit((0, 0, 0), 100.0, True, (0, 0, 0), (0, 0, 1))  # inside, inverted normal
+    assert t == 100.0 and np.array_equal(n, [0, 0, -1]) and np.array_equal(p, [0, 0, 100])
+    assert O.sphere_hit((0, 0, 0), 1.0, False, (0, 0, 5), (0, 0, 1)) is None     # behind the ray
+    assert O.sphere_hit((0, 0, 0), 1.0, False, (0, 2, -5), (0, 0, 1)) is None    # misses
+    # origin on the surface: near root t=0 <= T_MIN is rejected, far root accepted
+    t, n, p = O.sphere_hit((0, 0, 0), 1.0, False, (0, 0, -1), (0, 0, 1))
+    assert t == 2.0 and np.array_equal(n, [0, 0, 1])
+    # non-unit direction: a = d.d is honoured (shapes.rs:177)
+    t, _, p = O.sphere_hit((0, 0, 0), 1.0, False, (0, 0, -5), (0, 0, 2))
+    assert t == 2.0 and np.array_equal(p, [0, 0, -1])
+
+
+def test_plane_hit_kat(oracle_mod):
+    O = oracle_mod  # shapes.rs:135-152
+    t, n, p = O.plane_hit((0, 0, 0), (0, 1, 0), (0, 1, 0), (0, -1, 0))
+    assert t == 1.0 and np.array_equal(n, [0, 1, 0]) and np.array_equal(p, [0, 0, 0])
+    assert O.plane_hit((0, 0, 0), (0, 1, 0), (0, 1, 0), (1, 0, 0)) is None         # t = -inf
+    t, n, p = O.plane_hit((0, 0, 0), (0, 1, 0), (0, -1, 0), (1, 0, 0))            # t = +inf: a hit (quirk)
+    assert math.isinf(t) and t > 0
+    # two-sided, normal never flipped or normalised
+    t, n, _ = O.plane_hit((0, 0, 0), (0, 2, 0), (0, -3, 0), (0, 1, 0))
+    assert t == 3.0 and np.array_equal(n, [0, 2, 0])
+
+
+def test_bbox_hit_kat(oracle_mod):
+    O = oracle_mod  # shapes.rs:98-133
+    c0, c1 = (-1, -1, -1), (1, 1, 1)
+    assert O.bbox_hit(c0, c1, (0, 0, -5), (0, 0, 1))          # +-inf reciprocals on x,y
+    assert not O.bbox_hit(c0, c1, (0, 0, 5), (0, 0, 1))       # box behind: t1 < T_MIN
+    assert not O.bbox_hit(c0, c1, (2, 0, -5), (0, 0, 1))      # outside the x slab: t0 = +inf
+    assert O.bbox_hit(c0, c1, (0.5, 0.5, 0.5), (-1, -1, -1))  # origin inside, negative direction
+    # origin exactly on a slab plane with zero direction component: 0*inf = NaN through the
+    # file's own min/max (a > b ? a : b).  NaN in the outer `a` slot is dropped ...
+    assert O.bbox_hit(c0, c1, (-1, 0, -5), (0, 0, 1))
+    assert O.bbox_hit(c0, c1, (1, 0, -5), (0, 0, 1))
+    # ... NaN in an inner slot propagates and the test fails.
+    assert not O.bbox_hit(c0, c1, (-5, 0, -1), (1, 0, 0))
+    assert not O.bbox_hit(c0, c1, (-5, 0, 1), (1, 0, 0))
+
+
+def test_tie_break_lowest_index(oracle_mod, flux, demo1):
+    """scene.rs:156-160 + common.rs:17-23: equal distances keep the earlier shape."""
+    import copy
+    sd = copy.deepcopy(small_scene(demo1, 8, 6))
+    a = flux.SphereData((0, 0, 0), 1.0, flux.EmissiveData((1, 0, 0), 1.0), False)
+    b = flux.SphereData((0, 0, 0), 1.0, flux.EmissiveData((0, 1, 0), 1.0), False)
+    cfg = flux.JobConfiguration(1, 5, 50)
+    sd.shapes = [a, b]
+    o = oracle_mod.Oracle(sd, cfg)
+    assert o.scene_hit((0, 0, -5), (0, 0, 1))[0] == 0
+    assert np.array_equal(o.shade((0, 0, -5), (0, 0, 1), 1, 0, 0), [1, 0, 0])
+    sd.shapes = [b, a]
+    o = oracle_mod.Oracle(sd, cfg)
+    assert np.array_equal(o.shade((0, 0, -5), (0, 0, 1), 1, 0, 0), [0, 1, 0])
+    # +inf plane hit loses to any finite hit, wins when alone
+    pl = flux.PlaneData((0, 0, 0), (0, 1, 0), flux.EmissiveData((0, 0, 1), 1.0))
+    sd.shapes = [pl, a]
+    o = oracle_mod.Oracle(sd, cfg)
+    assert o.scene_hit((-5, -2, 0), (1, 0, 0))[0] == 0      # only the plane, at t = +inf
+    assert o.scene_hit((-5, -0.5, 0), (1, 0, 0))[0] == 1    # plane at +inf AND sphere at finite t
+
+
+# ------------------------------------------------------------ BRDFs / shading
+def test_brdf_weights(oracle_mod):
+    O = oracle_mod
+    n = np.array([0.0, 1.0, 0.0])
+    wo = np.array([0.6, 0.8, 0.0])
+    # Lambertian (brdf.rs:19-31): f * (n.wi)/pdf = colour*kd up to pi*INV_PI rounding
+    mat = [0.5, 0.3, 0.8, 1, 1, 1, 0.9, 0]
+    wi, pdf, f = O.sample_f(O.MAT_MATTE, mat, n, wo, hemi=(0.3, 0.4, math.sqrt(0.75)))
+    assert abs(np.linalg.norm(wi) - 1) < 1e-15 and wi @ n > 0
+    assert np.allclose(f * ((wi @ n) / pdf), np.array([0.5, 0.3, 0.8]) * 0.9, rtol=1e-15)
+    assert f == pytest.approx(np.array([0.5, 0.3, 0.8]) * 0.9 / math.pi, rel=1e-15)
+    # hemi sample (0,0,1) maps to the normal itself
+    wi, _, _ = O.sample_f(O.MAT_MATTE, mat, n, wo, hemi=(0, 0, 1))
+    assert np.allclose(wi, n, atol=1e-15)
+    # PerfectSpecular (brdf.rs:38-46): mirror direction, scale exactly 1
+    wi, pdf, f = O.sample_f(O.MAT_REFLECTIVE, [0.9, 1.0, 0.7, 0.5, 0, 0, 0, 0], n, wo)
+    assert np.allclose(wi, [-0.6, 0.8, 0.0], atol=1e-15) and (wi @ n) / pdf == 1.0
+    assert np.array_equal(f, np.array([0.9, 1.0, 0.7]) * 0.5)
+    # GlossySpecular (brdf.rs:54-79): f * (n.wi)/pdf = cs*ks to rounding, for every exponent
+    for e in (10.0, 100.0, 1e4, 1e5):
+        for sq in ((0.1, 0.2), (0.7, 0.9), (0.5, 0.999)):
+            wi, pdf, f = O.sample_f(O.MAT_GLOSSY, [0.8, 0.6, 1.0, 0.5, e, 0, 0, 0], n, wo, sq=sq)
+            assert np.allclose(f * ((wi @ n) / pdf), np.array([0.8, 0.6, 1.0]) * 0.5, rtol=1e-13)
+    # sample (x, 0) is the mirror direction itself
+    wi, _, _ = O.sample_f(O.MAT_GLOSSY, [1, 1, 1, 1, 50.0, 0, 0, 0], n, wo, sq=(0.3, 0.0))
+    assert np.allclose(wi, [-0.6, 0.8, 0.0], atol=1e-15)
+    # grazing view: lobe sample below the surface gets reflected back (brdf.rs:67-71)
+    wo_g = np.array([math.sqrt(1 - 0.01 ** 2), 0.01, 0.0])
+    below = 0
+    for x in np.linspace(0.0, 0.99, 34):
+        wi, _, _ = O.sample_f(O.MAT_GLOSSY, [1, 1, 1, 1, 5.0, 0, 0, 0], n, wo_g, sq=(x, 0.9))
+        below += wi @ n < 0
+    assert below < 34  # most are flipped above; the reference does not re-check (some may stay below)
+
+
+def test_emissive_and_depth(oracle_mod, flux, demo1):
+    """materials.rs:41-50: emits only towards the side the normal faces; scene.rs:164-165: depth > D -> black."""
+    import copy
+    sd = copy.deepcopy(small_scene(demo1, 8, 6))
+    sd.shapes = [flux.SphereData((0, 0, 0), 1.0, flux.EmissiveData((1, 0.5, 0.25), 2.0), False)]
+    o = oracle_mod.Oracle(sd, flux.JobConfiguration(1, 2, 50))
+    assert np.array_equal(o.shade((0, 0, -5), (0, 0, 1), 1, 0, 0), [2.0, 1.0, 0.5])
+    assert np.array_equal(o.shade((0, 0, 0), (0, 0, 1), 1, 0, 0), [0, 0, 0])     # from inside: back side
+    assert np.array_equal(o.shade((0, 0, -5), (0, 0, 1), 3, 0, 0), [0, 0, 0])    # depth 3 > D = 2
+    assert np.array_equal(o.shade((0, 5, -5), (0, 0, 1), 1, 0, 0), sd.background)  # miss
+
+
+def test_primary_ray(oracle_mod, flux, demo2):
+    """trace.rs:72-80: note (img_h - row), not (img_h - 1 - row)."""
+    sd = small_scene(demo2, 8, 6)
+    o = oracle_mod.Oracle(sd, flux.JobConfiguration(1, 5, 50), seed=3)
+    pix, disc = o.pixel_sets(), o.disc_sets()
+    U, V, Wv = o.camera_basis()
+    eye = np.array(sd.camera_settings.eye)
+    ps = sd.output_settings.pixel_size / sd.camera_data.zoom_factor
+    for row, col, s in [(0, 0, 0), (5, 7, 3), (2, 4, 7)]:
+        org, d = o.primary_ray(row, col, s, 0)
+        x = ps * (col - 4.0 + pix[s, 0, 0])
+        y = ps * ((6 - row) - 3.0 + pix[s, 0, 1])
+        lx, ly = disc[s, 0] * sd.camera_data.lens_radius
+        k = sd.camera_data.focal_distance / sd.camera_data.view_plane_distance
+        v = (x * k - lx) * U + (y * k - ly) * V - sd.camera_data.focal_distance * Wv
+        assert np.allclose(d, v / np.linalg.norm(v), atol=1e-15)
+        assert np.allclose(org, eye + lx * U + ly * V, atol=1e-15)
+
+
+# ------------------------------------------------------------- colour / image
+def test_max_to_one(oracle_mod):
+    O = oracle_mod  # color.rs:35-44
+    assert np.array_equal(O.max_to_one([2, 1, 0.5]), [1, 0.5, 0.25])
+    assert np.array_equal(O.max_to_one([0.5, 0.2, 0.1]), [0.5, 0.2, 0.1])
+    assert np.array_equal(O.max_to_one([1.0, 1.0, 1.0]), [1, 1, 1])
+    assert np.array_equal(O.max_to_one([0.1, 0.2, 4.0]), [0.025, 0.05, 1.0])
+
+
+def test_ppm_quantize(oracle_mod):
+    O = oracle_mod  # image.rs:50-53
+    assert O.ppm_quantize(1.0) == 65535 and O.ppm_quantize(0.5) == 32767 and O.ppm_quantize(0.0) == 0
+    assert O.ppm_quantize(-0.5) == 0 and O.ppm_quantize(float("nan")) == 0 and O.ppm_quantize(7.0) == 65535
+
+
+def test_work_units(oracle_mod):
+    O = oracle_mod  # job.rs:65-88
+    u = O.work_units(600, 50)
+    assert len(u) == 12 and u[0] == (0, 49) and u[-1] == (550, 599)
+    u = O.work_units(600, 1)
+    assert len(u) == 599 and u[-1] == (598, 598)       # row 599 is never issued (i < H-1 guard)
+    u = O.work_units(601, 50)
+    assert u[-1] == (550, 599) and len(u) == 12        # trailing single row dropped
+    assert O.work_units(600, 1000) == [(0, 599)]
+    assert O.work_units(1, 50) == []                   # H-1 == 0: no unit at all
+    with pytest.raises(ValueError):
+        O.work_units(600, 0)
+
+
+def test_ppm_writer(oracle_mod, tmp_path):
+    img = np.zeros((3, 2, 3))
+    img[0, 0] = [1.0, 0.5, 0.0]
+    img[2, 1] = [0.25, 0.25, 0.25]
+    path = str(tmp_path / "t.ppm")
+    oracle_mod.write_ppm(path, img, rows_present=[1, 0, 1])
+    lines = open(path).read().splitlines()
+    assert lines[:3] == ["P3", "2 3", "65535"]
+    assert lines[3] == "65535 32767 0" and lines[5] == "0 0 0" and lines[6] == "0 0 0"
+    assert lines[8] == "16383 16383 16383" and len(lines) == 3 + 6
+
+
+# ------------------------------------------------------------------- fixtures
+@pytest.mark.parametrize("name", ["demo1", "demo2"])
+def test_oracle_reproduces_golden(oracle_mod, flux, demo1, demo2, name):
+    """tests/golden/make_goldens.py output; allows for libm differences between machines."""
+    sd = small_scene(demo1 if name == "demo1" else demo2, 64, 48)
+    img = oracle_mod.Oracle(sd, flux.JobConfiguration(4, 5, 50), seed=1).render_frame(threads=4)
+    want = np.load(os.path.join(GOLDEN, f"{name}_64x48_n4_seed1.npy"))
+    assert np.max(np.abs(img - want)) < 1e-9
+
+
+def test_threads_do_not_change_the_image(oracle_mod, flux, demo2):
+    sd = small_scene(demo2, 40, 30)
+    o = oracle_mod.Oracle(sd, flux.JobConfiguration(3, 5, 50), seed=2)
+    a = o.render_frame(threads=1)
+    b = o.render_frame(threads=5)
+    assert np.array_equal(a, b)
+    c = np.concatenate([o.render_rows(0, 9), o.render_rows(10, 29, threads=3)], axis=0)
+    assert np.array_equal(a, c)
+    st = o.stats(reset=True)
+    assert st["samples"] == 3 * 40 * 30 * 9
+    assert st["segments"] == st["matte_bounces"] + st["glossy_bounces"] + st["specular_bounces"] + \
+        st["emissive_hits"] + st["misses"]
+
+
+def test_oracle_matches_reference_demo_png(oracle_mod, flux, demo2):
+    """Statistical pin against the reference's only published render (demo.png, demo2.yml at
+    16384 spp): 8x8 box-filtered means.  Different RNG and 8-bit source, so the bound is Monte-Carlo
+    noise + quantisation, not equality."""
+    ref = np.load(os.path.join(GOLDEN, "demo2_ref_100x75.npy")).astype(np.float64)
+    o = oracle_mod.Oracle(demo2, flux.JobConfiguration(8, 5, 50), seed=1)  # 64 spp
+    img = o.render_frame(threads=8)
+    small = img.reshape(75, 8, 100, 8, 3).mean(axis=(1, 3))
+    d = small - ref
+    assert np.abs(d).mean() < 0.01, np.abs(d).mean()   # measured 0.0071
+    assert np.all(np.abs(d.mean(axis=(0, 1))) < 0.004), d.mean(axis=(0, 1))  # no colour bias
+    # orientation: the area-light glow is top-right, the far spheres go top-left (U = (-1,0,0))
+    assert small[:20, 60:].mean() > small[:20, :40].mean()
