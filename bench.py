@@ -34,8 +34,20 @@ def parse():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--kernel", type=int, default=0, help="0 default, 1 static, 2 refill")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-root", type=int, default=16, help="sample_root of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-root", type=int, default=32, help="sample_root of the bounded CPU-baseline sample")
     return ap.parse_args()
+
+
+def host_cores():
+    """CPU threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
 
 
 def cpu_baseline(sd, depth, seed, cpu_root):
@@ -43,7 +55,7 @@ def cpu_baseline(sd, depth, seed, cpu_root):
     bounded sample: the SAME scene, full frame, at cpu_root^2 spp (cost is linear in spp)."""
     import flux_amd
     from oracle import oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     cfg = flux_amd.JobConfiguration(cpu_root, depth, 50)
     t0 = time.perf_counter()
     o = oracle.Oracle(sd, cfg, seed=seed)

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflux_hip.so")
+# FLUX_HIP_LIB: experiment builds of the same sources (scripts/sweep_variants.py); never a fallback.
+LIB_PATH = os.environ.get("FLUX_HIP_LIB") or os.path.join(_HERE, "libflux_hip.so")
 
 FLUX_OK = 0
 E_INVALID, E_DEVICE, E_NOMEM, E_IO = -1, -2, -3, -4

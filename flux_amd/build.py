@@ -34,6 +34,17 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+def build_variant(out_path, extra_flags, verbose=False):
+    """Experiment builds (scripts/sweep_variants.py): same sources, extra -D/-f flags."""
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    flags = [f for f in HIP_FLAGS if not (f == "-ffp-contract=off" and any(x.startswith("-ffp-contract") for x in extra_flags))]
+    cmd = [_hipcc()] + flags + list(extra_flags) + ["-o", out_path] + srcs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return out_path
+
+
 def build_hip(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(ROOT, "include", "flux_abi.h")]

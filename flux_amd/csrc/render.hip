@@ -32,6 +32,17 @@
 #include "flux_tables.h"
 #include "../../include/flux_abi.h"
 
+// Tunables (overridable with -D for experiments, scripts/sweep_variants.py).  Measured on demo2 at
+// 1024 spp (refill kernel): 256 threads x 2 waves/SIMD 88.6 ms; 256 x 3 71.7 ms; 64 x 3 70.7 ms;
+// 256 x 4 83.0 ms (spills).  Waves never cooperate, so one wave per block lets the LDS stack of a
+// finished wave be reused at once.
+#ifndef FLUX_BLOCK_THREADS
+#define FLUX_BLOCK_THREADS 64
+#endif
+#ifndef FLUX_WAVES_PER_EU
+#define FLUX_WAVES_PER_EU 3
+#endif
+
 namespace flux {
 
 struct Ray {
@@ -324,7 +335,7 @@ __device__ __forceinline__ void flush_stats(const RenderParams &P, Stats &st, ui
 // Handles every n (also n*n < 64: 64/(n*n) pixels share a wave).
 // ---------------------------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__(256) void render_static_kernel(const RenderParams P) {
+__global__ __launch_bounds__(FLUX_BLOCK_THREADS, FLUX_WAVES_PER_EU) void render_static_kernel(const RenderParams P) {
     extern __shared__ double lds_stack[];
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63;
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(256) void render_static_kernel(const RenderParams P
 // next unstarted samples.
 // ---------------------------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__(256) void render_refill_kernel(const RenderParams P) {
+__global__ __launch_bounds__(FLUX_BLOCK_THREADS, FLUX_WAVES_PER_EU) void render_refill_kernel(const RenderParams P) {
     extern __shared__ double lds_stack[];
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63;
@@ -464,8 +475,9 @@ hipError_t launch_render(const RenderParams &p, int variant, hipStream_t stream)
     const uint32_t lpp = N >= 64u ? 64u : N;
     const uint32_t ppw = 64u / lpp;
     const uint64_t waves = (npix + ppw - 1) / ppw;
-    const unsigned block = 256;
-    const uint64_t blocks = (waves + 3) / 4;
+    const unsigned block = FLUX_BLOCK_THREADS;
+    const unsigned wpb = block / 64;
+    const uint64_t blocks = (waves + wpb - 1) / wpb;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = (size_t)p.max_depth * 4 * block * sizeof(double);
     const bool stats = p.stats != nullptr;
