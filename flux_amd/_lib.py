@@ -17,6 +17,8 @@ SHAPE_SPHERE, SHAPE_PLANE = 0, 1
 MAT_MATTE, MAT_EMISSIVE, MAT_REFLECTIVE, MAT_GLOSSY = 0, 1, 2, 3
 KERNEL_DEFAULT, KERNEL_STATIC, KERNEL_REFILL = 0, 1, 2
 TABLE_PIXEL, TABLE_DISC, TABLE_HEMI = 0, 1, 2
+TRAVERSE_BVH, TRAVERSE_BRUTE = 0, 1
+NUM_STATS = 16
 
 
 class FluxMaterial(C.Structure):
@@ -29,12 +31,18 @@ class FluxShape(C.Structure):
                 ("radius", C.c_double), ("material", FluxMaterial)]
 
 
+class FluxMesh(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint64), ("vertices", C.POINTER(C.c_double)),
+                ("num_triangles", C.c_uint64), ("indices", C.POINTER(C.c_uint32)), ("material", FluxMaterial)]
+
+
 class FluxSceneDesc(C.Structure):
     _fields_ = [("scene_name", C.c_char_p), ("image_width", C.c_uint64), ("image_height", C.c_uint64),
                 ("pixel_size", C.c_double), ("background", C.c_double * 3), ("eye", C.c_double * 3),
                 ("look_at", C.c_double * 3), ("up", C.c_double * 3), ("zoom_factor", C.c_double),
                 ("view_plane_distance", C.c_double), ("focal_distance", C.c_double),
-                ("lens_radius", C.c_double), ("num_shapes", C.c_uint64), ("shapes", C.POINTER(FluxShape))]
+                ("lens_radius", C.c_double), ("num_shapes", C.c_uint64), ("shapes", C.POINTER(FluxShape)),
+                ("num_meshes", C.c_uint64), ("meshes", C.POINTER(FluxMesh))]
 
 
 class FluxJobCfg(C.Structure):
@@ -64,6 +72,8 @@ SYMBOLS = {
     "flux_render_rows": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]),
     "flux_render_rows_device": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P]),
     "flux_ctx_set_kernel": (C.c_int, [_P, C.c_int]),
+    "flux_ctx_set_traversal": (C.c_int, [_P, C.c_int]),
+    "flux_ctx_bvh_info": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "flux_ctx_last_kernel_ms": (C.c_double, [_P]),
     "flux_ctx_enable_stats": (C.c_int, [_P, C.c_int]),
     "flux_ctx_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),

@@ -67,6 +67,11 @@ struct flux_ctx {
     int32_t *d_rowperm = nullptr;
     unsigned long long *d_stats = nullptr;
     bool stats_on = false;
+    // extension: triangle meshes
+    flux::DevTri *d_tris = nullptr;
+    flux::DevNode *d_nodes = nullptr;
+    flux::BvhInfo bvh{};
+    int traversal = FLUX_TRAVERSE_BVH;
     int variant = FLUX_KERNEL_DEFAULT;
     // scratch framebuffer for the host-output path
     double *d_out = nullptr;
@@ -101,6 +106,8 @@ static void free_ctx(flux_ctx *c) {
     (void)hipFree(c->d_hemi);
     (void)hipFree(c->d_rowperm);
     (void)hipFree(c->d_stats);
+    (void)hipFree(c->d_tris);
+    (void)hipFree(c->d_nodes);
     (void)hipFree(c->d_out);
     delete c;
 }
@@ -117,6 +124,21 @@ static void cross3(const double a[3], const double b[3], double o[3]) {
     o[0] = a[1] * b[2] - a[2] * b[1];
     o[1] = a[2] * b[0] - a[0] * b[2];
     o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// material_from_data (scene.rs:87-125) + the per-material constants of brdf.rs:30,45,76 / materials.rs:45
+static void fill_material(flux::DevMaterial &dm, const flux_material &m) {
+    dm.kind = m.kind;
+    dm.exponent = m.exponent;
+    dm.inv_e1 = 1.0 / (m.exponent + 1.0);
+    double f[3];
+    for (int ch = 0; ch < 3; ch++) {
+        f[ch] = m.color[ch] * m.k;
+        if (m.kind == FLUX_MAT_MATTE) f[ch] = f[ch] * flux::kInvPi;  // brdf.rs:30
+    }
+    dm.fr = f[0];
+    dm.fg = f[1];
+    dm.fb = f[2];
 }
 
 int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint64_t seed, int device,
@@ -146,6 +168,23 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
             return fail(FLUX_E_INVALID, "shape %llu: unknown material kind %d", (unsigned long long)i,
                         s.material.kind);
     }
+    if (scene->num_meshes > 0 && !scene->meshes)
+        return fail(FLUX_E_INVALID, "num_meshes > 0 but meshes is null");
+    uint64_t total_tris = 0;
+    for (uint64_t m = 0; m < scene->num_meshes; m++) {
+        const flux_mesh &me = scene->meshes[m];
+        if (me.material.kind < FLUX_MAT_MATTE || me.material.kind > FLUX_MAT_GLOSSY)
+            return fail(FLUX_E_INVALID, "mesh %llu: unknown material kind %d", (unsigned long long)m, me.material.kind);
+        if (me.num_triangles && (!me.vertices || !me.indices))
+            return fail(FLUX_E_INVALID, "mesh %llu: null vertices/indices", (unsigned long long)m);
+        for (uint64_t k = 0; k < 3 * me.num_triangles; k++)
+            if (me.indices[k] >= me.num_vertices)
+                return fail(FLUX_E_INVALID, "mesh %llu: vertex index %u out of range (%llu vertices)",
+                            (unsigned long long)m, me.indices[k], (unsigned long long)me.num_vertices);
+        total_tris += me.num_triangles;
+    }
+    if (total_tris > (1ull << 30))
+        return fail(FLUX_E_INVALID, "too many triangles: %llu", (unsigned long long)total_tris);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(FLUX_E_DEVICE, "no HIP device visible (this library has no CPU fallback)");
@@ -168,7 +207,7 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     // ---- Scene::from_data: per-shape constants -------------------------------
     const size_t ns = (size_t)scene->num_shapes;
     std::vector<flux::DevShape> shapes(ns ? ns : 1);
-    std::vector<flux::DevMaterial> mats(ns ? ns : 1);
+    std::vector<flux::DevMaterial> mats(ns + (size_t)scene->num_meshes + 1);
     std::memset(shapes.data(), 0, shapes.size() * sizeof(flux::DevShape));
     std::memset(mats.data(), 0, mats.size() * sizeof(flux::DevMaterial));
     for (size_t i = 0; i < ns; i++) {
@@ -194,17 +233,40 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
             d.c0y = s.n[1];
             d.c0z = s.n[2];
         }
-        // material_from_data: scene.rs:87-125
-        const flux_material &m = s.material;
-        flux::DevMaterial &dm = mats[i];
-        dm.kind = m.kind;
-        dm.exponent = m.exponent;
-        dm.inv_e1 = 1.0 / (m.exponent + 1.0);
-        for (int ch = 0; ch < 3; ch++) {
-            double v = m.color[ch] * m.k;
-            if (m.kind == FLUX_MAT_MATTE) v = v * flux::kInvPi;  // brdf.rs:30
-            (&dm.fr)[ch] = v;
+        fill_material(mats[i], s.material);
+    }
+    // extension: meshes -> triangle records (hit order: after all shapes) + BVH
+    std::vector<flux::DevTri> tris;
+    std::vector<flux::DevNode> nodes;
+    tris.reserve((size_t)total_tris);
+    for (uint64_t m = 0; m < scene->num_meshes; m++) {
+        const flux_mesh &me = scene->meshes[m];
+        fill_material(mats[ns + (size_t)m], me.material);
+        for (uint64_t k = 0; k < me.num_triangles; k++) {
+            const double *a = me.vertices + 3 * (size_t)me.indices[3 * k];
+            const double *b = me.vertices + 3 * (size_t)me.indices[3 * k + 1];
+            const double *d = me.vertices + 3 * (size_t)me.indices[3 * k + 2];
+            flux::DevTri t;
+            std::memset(&t, 0, sizeof(t));
+            t.v0x = a[0]; t.v0y = a[1]; t.v0z = a[2];
+            t.e1x = b[0] - a[0]; t.e1y = b[1] - a[1]; t.e1z = b[2] - a[2];
+            t.e2x = d[0] - a[0]; t.e2y = d[1] - a[1]; t.e2z = d[2] - a[2];
+            const double e1[3] = {t.e1x, t.e1y, t.e1z}, e2[3] = {t.e2x, t.e2y, t.e2z};
+            double nn[3], nu[3];
+            cross3(e1, e2, nn);
+            normalize3(nn, nu);
+            t.nx = nu[0]; t.ny = nu[1]; t.nz = nu[2];
+            t.id = (int32_t)(ns + tris.size());
+            t.mat = (int32_t)(ns + m);
+            tris.push_back(t);
         }
+    }
+    flux::build_bvh(tris, nodes, c->bvh);
+    if (c->bvh.max_depth > (uint64_t)flux::kBvhMaxDepth) {
+        int code = fail(FLUX_E_INVALID, "BVH depth %llu exceeds %d (degenerate mesh)",
+                        (unsigned long long)c->bvh.max_depth, flux::kBvhMaxDepth);
+        delete c;
+        return code;
     }
 
     // ---- CameraBasis::new: scene.rs:28-35 --------------------------------------
@@ -262,10 +324,16 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     alloc((void **)&c->d_disc, pix_bytes);
     alloc((void **)&c->d_hemi, hemi_bytes);
     alloc((void **)&c->d_rowperm, perm_bytes);
-    alloc((void **)&c->d_stats, 8 * sizeof(unsigned long long));
+    alloc((void **)&c->d_stats, FLUX_NUM_STATS * sizeof(unsigned long long));
+    if (!tris.empty()) {
+        alloc((void **)&c->d_tris, tris.size() * sizeof(flux::DevTri));
+        alloc((void **)&c->d_nodes, nodes.size() * sizeof(flux::DevNode));
+        if (e == hipSuccess) e = hipMemcpy(c->d_tris, tris.data(), tris.size() * sizeof(flux::DevTri), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->d_nodes, nodes.data(), nodes.size() * sizeof(flux::DevNode), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMemcpy(c->d_shapes, shapes.data(), shapes.size() * sizeof(flux::DevShape), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_mats, mats.data(), mats.size() * sizeof(flux::DevMaterial), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(c->d_stats, 0, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(c->d_stats, 0, FLUX_NUM_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     // ---- MasterSampleSets::new on the device (sampling.rs:13-33) --------------
@@ -284,6 +352,10 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     rp.hemi = c->d_hemi;
     rp.rowperm = c->d_rowperm;
     rp.stats = nullptr;
+    rp.tris = c->d_tris;
+    rp.nodes = c->d_nodes;
+    rp.n_tris = (int32_t)tris.size();
+    rp.bvh_stack = (int32_t)c->bvh.max_depth;
     *out = c;
     return FLUX_OK;
 }
@@ -315,6 +387,7 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
     p.row_stride = (int32_t)row_stride;
     p.num_rows = (int32_t)num_rows;
     p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
+    if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(flux::launch_render(p, ctx->variant, stream));
     HIP_TRY(hipEventRecord(ctx->ev1, stream));
@@ -360,13 +433,34 @@ int flux_ctx_enable_stats(flux_ctx *ctx, int on) {
     return FLUX_OK;
 }
 
-int flux_ctx_stats(flux_ctx *ctx, uint64_t out[8], int reset) {
+int flux_ctx_set_traversal(flux_ctx *ctx, int mode) {
+    if (!ctx) return fail(FLUX_E_INVALID, "null context");
+    if (mode != FLUX_TRAVERSE_BVH && mode != FLUX_TRAVERSE_BRUTE)
+        return fail(FLUX_E_INVALID, "unknown traversal mode %d", mode);
+    ctx->traversal = mode;
+    return FLUX_OK;
+}
+
+int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t out[8]) {
+    if (!ctx || !out) return fail(FLUX_E_INVALID, "null argument");
+    out[0] = ctx->bvh.nodes;
+    out[1] = ctx->bvh.tris;
+    out[2] = ctx->bvh.max_depth;
+    out[3] = ctx->bvh.max_leaf;
+    out[4] = sizeof(flux::DevNode);
+    out[5] = sizeof(flux::DevTri);
+    out[6] = ctx->bvh.build_us;
+    out[7] = 0;
+    return FLUX_OK;
+}
+
+int flux_ctx_stats(flux_ctx *ctx, uint64_t out[FLUX_NUM_STATS], int reset) {
     if (!ctx || !out) return fail(FLUX_E_INVALID, "null argument");
     DeviceGuard guard(ctx->device);
     HIP_TRY(hipDeviceSynchronize());
-    unsigned long long tmp[8];
+    unsigned long long tmp[FLUX_NUM_STATS];
     HIP_TRY(hipMemcpy(tmp, ctx->d_stats, sizeof(tmp), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; i++) out[i] = tmp[i];
+    for (int i = 0; i < FLUX_NUM_STATS; i++) out[i] = tmp[i];
     if (reset) HIP_TRY(hipMemset(ctx->d_stats, 0, sizeof(tmp)));
     return FLUX_OK;
 }

@@ -1,0 +1,257 @@
+// bvh.cpp -- host-side BVH builder for triangle meshes (extension; no reference counterpart).
+//
+// Top-down binned SAH (16 bins, all three axes), leaves of <= kBvhLeafSize triangles, depth bounded
+// by falling back to median splits, children bounds stored in the parent as outward-rounded, padded
+// f32 so that the device slab test never rejects a box whose triangle the f64 Moeller-Trumbore test
+// would accept.  The traversal must return exactly the brute-force nearest hit (lowest id on ties).
+#include "flux_bvh.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace flux {
+namespace {
+
+struct Box {
+    double lo[3], hi[3];
+    void reset() {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::numeric_limits<double>::infinity();
+            hi[a] = -std::numeric_limits<double>::infinity();
+        }
+    }
+    void grow(const Box &b) {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], b.lo[a]);
+            hi[a] = std::max(hi[a], b.hi[a]);
+        }
+    }
+    void grow(const double p[3]) {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], p[a]);
+            hi[a] = std::max(hi[a], p[a]);
+        }
+    }
+    double area() const {
+        double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0;
+        return 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct Prim {
+    Box box;
+    double c[3];
+};
+
+struct Builder {
+    const std::vector<Prim> &prims;
+    std::vector<uint32_t> order;
+    std::vector<DevNode> &nodes;
+    double pad;
+    BvhInfo &info;
+
+    static float down(double x) {
+        float f = (float)x;
+        if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity());
+        return f;
+    }
+    static float up(double x) {
+        float f = (float)x;
+        if ((double)f < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity());
+        return f;
+    }
+    void store_box(float lo[3], float hi[3], const Box &b) const {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = down(b.lo[a] - pad);
+            hi[a] = up(b.hi[a] + pad);
+        }
+    }
+    static void empty_box(float lo[3], float hi[3]) {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::numeric_limits<float>::infinity();
+            hi[a] = -std::numeric_limits<float>::infinity();
+        }
+    }
+
+    Box range_box(uint32_t b, uint32_t e) const {
+        Box r;
+        r.reset();
+        for (uint32_t k = b; k < e; k++) r.grow(prims[order[k]].box);
+        return r;
+    }
+
+    // Chooses a split position in (b,e); partitions order[b,e) accordingly.
+    uint32_t split(uint32_t b, uint32_t e, int depth) {
+        const uint32_t n = e - b;
+        Box cb;
+        cb.reset();
+        for (uint32_t k = b; k < e; k++) cb.grow(prims[order[k]].c);
+        int best_axis = -1, best_bin = -1;
+        double best_cost = std::numeric_limits<double>::infinity();
+        constexpr int NB = 16;
+        const bool allow_sah = depth < kBvhSahDepth;
+        if (allow_sah) {
+            for (int a = 0; a < 3; a++) {
+                const double ext = cb.hi[a] - cb.lo[a];
+                if (!(ext > 0.0)) continue;
+                Box bb[NB];
+                uint32_t cnt[NB];
+                for (int i = 0; i < NB; i++) {
+                    bb[i].reset();
+                    cnt[i] = 0;
+                }
+                const double k1 = NB * (1.0 - 1e-12) / ext;
+                for (uint32_t k = b; k < e; k++) {
+                    const Prim &p = prims[order[k]];
+                    int bin = (int)((p.c[a] - cb.lo[a]) * k1);
+                    bin = std::min(std::max(bin, 0), NB - 1);
+                    bb[bin].grow(p.box);
+                    cnt[bin]++;
+                }
+                double la[NB], ra[NB];
+                uint32_t lc[NB], rc[NB];
+                Box acc;
+                acc.reset();
+                uint32_t c = 0;
+                for (int i = 0; i < NB; i++) {
+                    acc.grow(bb[i]);
+                    c += cnt[i];
+                    la[i] = acc.area();
+                    lc[i] = c;
+                }
+                acc.reset();
+                c = 0;
+                for (int i = NB - 1; i >= 0; i--) {
+                    acc.grow(bb[i]);
+                    c += cnt[i];
+                    ra[i] = acc.area();
+                    rc[i] = c;
+                }
+                for (int i = 0; i < NB - 1; i++) {
+                    if (lc[i] == 0 || rc[i + 1] == 0) continue;
+                    double cost = la[i] * lc[i] + ra[i + 1] * rc[i + 1];
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        best_axis = a;
+                        best_bin = i;
+                    }
+                }
+            }
+        }
+        if (best_axis >= 0) {
+            const int a = best_axis;
+            const double ext = cb.hi[a] - cb.lo[a];
+            const double k1 = NB * (1.0 - 1e-12) / ext;
+            auto mid = std::partition(order.begin() + b, order.begin() + e, [&](uint32_t id) {
+                int bin = (int)((prims[id].c[a] - cb.lo[a]) * k1);
+                bin = std::min(std::max(bin, 0), NB - 1);
+                return bin <= best_bin;
+            });
+            uint32_t m = (uint32_t)(mid - order.begin());
+            if (m > b && m < e) return m;
+        }
+        // median split on the widest centroid axis (also the depth-bounding fallback)
+        int a = 0;
+        for (int k = 1; k < 3; k++)
+            if (cb.hi[k] - cb.lo[k] > cb.hi[a] - cb.lo[a]) a = k;
+        const uint32_t m = b + n / 2;
+        std::nth_element(order.begin() + b, order.begin() + m, order.begin() + e, [&](uint32_t x, uint32_t y) {
+            return prims[x].c[a] < prims[y].c[a] || (prims[x].c[a] == prims[y].c[a] && x < y);
+        });
+        return m;
+    }
+
+    // Builds the subtree over order[b,e) (more than one leaf's worth); returns its node index.
+    int32_t build_inner(uint32_t b, uint32_t e, int depth) {
+        const int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        info.max_depth = std::max<uint64_t>(info.max_depth, (uint64_t)depth + 1);
+        const uint32_t m = split(b, e, depth);
+        const uint32_t rb[2] = {b, m}, re[2] = {m, e};
+        for (int side = 0; side < 2; side++) {
+            const uint32_t cnt = re[side] - rb[side];
+            const Box bx = range_box(rb[side], re[side]);
+            int32_t link, count = 0;
+            if (cnt <= (uint32_t)kBvhLeafSize) {
+                link = ~(int32_t)rb[side];
+                count = (int32_t)cnt;
+                info.max_leaf = std::max<uint64_t>(info.max_leaf, cnt);
+            } else {
+                link = build_inner(rb[side], re[side], depth + 1);
+            }
+            DevNode &N = nodes[me];  // re-fetch: the vector may have grown
+            if (side == 0) {
+                store_box(N.lo0, N.hi0, bx);
+                N.child0 = link;
+                N.count0 = count;
+            } else {
+                store_box(N.lo1, N.hi1, bx);
+                N.child1 = link;
+                N.count1 = count;
+            }
+        }
+        return me;
+    }
+};
+
+}  // namespace
+
+void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &info) {
+    const auto t0 = std::chrono::steady_clock::now();
+    nodes.clear();
+    info = BvhInfo();
+    info.tris = tris.size();
+    if (tris.empty()) return;
+    std::vector<Prim> prims(tris.size());
+    Box all;
+    all.reset();
+    for (size_t k = 0; k < tris.size(); k++) {
+        const DevTri &t = tris[k];
+        const double v[3][3] = {{t.v0x, t.v0y, t.v0z},
+                                {t.v0x + t.e1x, t.v0y + t.e1y, t.v0z + t.e1z},
+                                {t.v0x + t.e2x, t.v0y + t.e2y, t.v0z + t.e2z}};
+        Prim &p = prims[k];
+        p.box.reset();
+        for (int j = 0; j < 3; j++) p.box.grow(v[j]);
+        for (int a = 0; a < 3; a++) p.c[a] = 0.5 * (p.box.lo[a] + p.box.hi[a]);
+        all.grow(p.box);
+    }
+    double diag = 0.0;
+    for (int a = 0; a < 3; a++) diag = std::max(diag, all.hi[a] - all.lo[a]);
+    double mag = 0.0;
+    for (int a = 0; a < 3; a++) mag = std::max(mag, std::max(std::fabs(all.lo[a]), std::fabs(all.hi[a])));
+    // absolute padding: far above the f64 rounding of the triangle test and the v0+e reconstruction,
+    // far below anything visible in traversal cost
+    const double pad = 1e-7 * std::max(std::max(diag, mag), 1e-30);
+
+    Builder B{prims, {}, nodes, pad, info};
+    B.order.resize(tris.size());
+    for (size_t k = 0; k < tris.size(); k++) B.order[k] = (uint32_t)k;
+    nodes.reserve(tris.size() / 2 + 4);
+    if (tris.size() <= (size_t)kBvhLeafSize) {
+        nodes.emplace_back();
+        DevNode &N = nodes[0];
+        B.store_box(N.lo0, N.hi0, all);
+        N.child0 = ~0;
+        N.count0 = (int32_t)tris.size();
+        Builder::empty_box(N.lo1, N.hi1);
+        N.child1 = ~0;
+        N.count1 = 0;
+        info.max_depth = 1;
+        info.max_leaf = tris.size();
+    } else {
+        B.build_inner(0, (uint32_t)tris.size(), 0);
+    }
+    std::vector<DevTri> sorted(tris.size());
+    for (size_t k = 0; k < tris.size(); k++) sorted[k] = tris[B.order[k]];
+    tris.swap(sorted);
+    info.nodes = nodes.size();
+    info.build_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
+                        std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace flux

@@ -1,0 +1,44 @@
+// flux_bvh.h -- triangle records and the flattened BVH (extension; the reference has neither
+// triangles nor a BVH: fluxcore/src/scene.rs:71-74, 156-160).  DESIGN.md "Triangles and the BVH".
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+namespace flux {
+
+// One triangle = one 128-B line: everything Moeller-Trumbore needs plus the stored normal.
+struct DevTri {
+    double v0x, v0y, v0z;
+    double e1x, e1y, e1z;  // v1 - v0
+    double e2x, e2y, e2z;  // v2 - v0
+    double nx, ny, nz;     // normalize(e1 x e2), never flipped
+    int32_t id;            // index in hit order: num_shapes + position in the input meshes
+    int32_t mat;           // index into the material array
+    double pad[3];
+};
+static_assert(sizeof(DevTri) == 128, "DevTri layout");
+
+// Binary BVH node, 64 B: the bounds of BOTH children (f32, rounded outward and padded, so the
+// slab test is conservative w.r.t. the f64 triangle test) and their links.
+// child >= 0: inner node index; child < 0: leaf holding triangles [~child, ~child + count).
+struct DevNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t child0, child1;
+    int32_t count0, count1;  // leaf triangle counts (0 for inner children; 0 + inverted box = empty)
+};
+static_assert(sizeof(DevNode) == 64, "DevNode layout");
+
+constexpr int kBvhSahDepth = 32;    // below this depth the builder uses SAH, deeper: median splits
+constexpr int kBvhMaxDepth = 64;    // hard limit; the per-lane LDS stack is sized max_depth entries
+constexpr int kBvhLeafSize = 4;
+
+struct BvhInfo {
+    uint64_t nodes = 0, tris = 0, max_depth = 0, max_leaf = 0, build_us = 0;
+};
+
+// Binned-SAH top-down build.  `tris` is reordered into leaf order (ids keep the original order).
+void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &info);
+
+}  // namespace flux

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "flux_bvh.h"
+
 namespace flux {
 
 constexpr double kTMin = 0.0005;                       // constants.rs:4
@@ -73,7 +75,12 @@ struct RenderParams {
     double *out;          // [num_rows][W][3]
     int32_t first_row, row_stride, num_rows;
     int32_t pad;
-    unsigned long long *stats;  // 8 counters or nullptr
+    unsigned long long *stats;  // FLUX_NUM_STATS counters or nullptr
+    // extension: triangle meshes (0 / nullptr for reference scenes)
+    const DevTri *tris;    // leaf order
+    const DevNode *nodes;  // node 0 = root
+    int32_t n_tris;
+    int32_t bvh_stack;     // per-lane traversal stack entries (= BVH max depth); 0 = brute force
 };
 
 }  // namespace flux

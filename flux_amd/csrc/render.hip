@@ -86,7 +86,106 @@ __device__ __forceinline__ Ray primary_ray(const RenderParams &P, int row, int c
 // Scene::hit (scene.rs:156-160): nearest of all shapes; a later shape replaces
 // the current best only when !(best <= t) (Hit::compare under min_by,
 // common.rs:17-23), so ties keep the lower index.  Returns -1 on miss.
-__device__ __forceinline__ int scene_hit(const RenderParams &P, const Ray &r, double &t_out) {
+// path statistics (STATS builds only)
+struct Stats {
+    unsigned c[10];
+};
+
+// ---- extension: triangles (no reference counterpart; DESIGN.md "Triangles and the BVH") ----------
+// Moeller-Trumbore, f64, two-sided; the CPU checker restates the same sequence of operations.
+__device__ __forceinline__ bool tri_hit(const DevTri &T, const Ray &r, double &t) {
+    const V3 d = mk(r.dx, r.dy, r.dz);
+    const V3 e1 = mk(T.e1x, T.e1y, T.e1z), e2 = mk(T.e2x, T.e2y, T.e2z);
+    const V3 p = cross(d, e2);
+    const double det = dot(e1, p);
+    if (det == 0.0) return false;
+    const double inv = 1.0 / det;
+    const V3 s = mk(r.ox - T.v0x, r.oy - T.v0y, r.oz - T.v0z);
+    const double u = dot(s, p) * inv;
+    if (u < 0.0 || u > 1.0) return false;
+    const V3 q = cross(s, e1);
+    const double v = dot(d, q) * inv;
+    if (v < 0.0 || u + v > 1.0) return false;
+    t = dot(e2, q) * inv;
+    return t > kTMin;
+}
+
+// nearest-hit rule of Scene::hit for candidates visited in ANY order: smaller t wins, equal t keeps
+// the lower hit-order index (what min_by + Hit::compare give for an ordered scan)
+__device__ __forceinline__ void consider(double t, int id, int slot, int &best, int &bslot, double &tb) {
+    if (best < 0 || t < tb || (t == tb && id < best)) {
+        best = id;
+        bslot = slot;
+        tb = t;
+    }
+}
+
+// conservative slab test against an f32 box (already padded by the builder); inv* are finite
+__device__ __forceinline__ bool box_hit(const float *lo, const float *hi, const Ray &r, double ix, double iy,
+                                        double iz, double tb, bool have, double &tnear) {
+    const double x0 = ((double)lo[0] - r.ox) * ix, x1 = ((double)hi[0] - r.ox) * ix;
+    const double y0 = ((double)lo[1] - r.oy) * iy, y1 = ((double)hi[1] - r.oy) * iy;
+    const double z0 = ((double)lo[2] - r.oz) * iz, z1 = ((double)hi[2] - r.oz) * iz;
+    const double tn = fmax(fmax(fmin(x0, x1), fmin(y0, y1)), fmin(z0, z1));
+    const double tf = fmin(fmin(fmax(x0, x1), fmax(y0, y1)), fmax(z0, z1));
+    tnear = tn;
+    return tn <= tf && tf >= 0.0 && (!have || tn <= tb);
+}
+
+template <bool STATS>
+__device__ __forceinline__ void bvh_traverse(const RenderParams &P, const Ray &r, int *tstack, int stride,
+                                             int &best, int &bslot, double &tb, Stats &st) {
+    // reciprocal direction with zero components nudged to +-1e-300: no inf*0 = NaN in the slab test
+    const double tiny = 1e-300;
+    const double ix = 1.0 / (fabs(r.dx) < tiny ? copysign(tiny, r.dx) : r.dx);
+    const double iy = 1.0 / (fabs(r.dy) < tiny ? copysign(tiny, r.dy) : r.dy);
+    const double iz = 1.0 / (fabs(r.dz) < tiny ? copysign(tiny, r.dz) : r.dz);
+    int sp = 0;
+    int cur = 0;
+    for (;;) {
+        const DevNode N = P.nodes[cur];
+        if (STATS) st.c[8]++;
+        double tn0, tn1;
+        bool h0 = box_hit(N.lo0, N.hi0, r, ix, iy, iz, tb, best >= 0, tn0);
+        bool h1 = box_hit(N.lo1, N.hi1, r, ix, iy, iz, tb, best >= 0, tn1);
+        if (h0 && N.child0 < 0) {
+            const int first = ~N.child0;
+            for (int k = 0; k < N.count0; ++k) {
+                double t;
+                if (STATS) st.c[9]++;
+                if (tri_hit(P.tris[first + k], r, t)) consider(t, P.tris[first + k].id, first + k, best, bslot, tb);
+            }
+            h0 = false;
+        }
+        if (h1 && N.child1 < 0) {
+            const int first = ~N.child1;
+            for (int k = 0; k < N.count1; ++k) {
+                double t;
+                if (STATS) st.c[9]++;
+                if (tri_hit(P.tris[first + k], r, t)) consider(t, P.tris[first + k].id, first + k, best, bslot, tb);
+            }
+            h1 = false;
+        }
+        if (h0 && h1) {
+            const bool near0 = tn0 <= tn1;
+            tstack[sp * stride] = near0 ? N.child1 : N.child0;
+            ++sp;
+            cur = near0 ? N.child0 : N.child1;
+        } else if (h0) {
+            cur = N.child0;
+        } else if (h1) {
+            cur = N.child1;
+        } else {
+            if (sp == 0) break;
+            --sp;
+            cur = tstack[sp * stride];
+        }
+    }
+}
+
+template <bool STATS, bool TRIS>
+__device__ __forceinline__ int scene_hit(const RenderParams &P, const Ray &r, double &t_out, int &slot_out,
+                                         int *tstack, int stride, Stats &st) {
     // BoundingBox::hit's reciprocals depend on the ray only (shapes.rs:107,114,121)
     const double ax = 1.0 / r.dx, ay = 1.0 / r.dy, az = 1.0 / r.dz;
     const double a = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;  // shapes.rs:177
@@ -138,7 +237,21 @@ __device__ __forceinline__ int scene_hit(const RenderParams &P, const Ray &r, do
             tb = t;
         }
     }
+    int bslot = -1;
+    if (TRIS) {
+        // triangles continue the scan with hit-order indices n_shapes + k
+        if (P.bvh_stack > 0) {
+            bvh_traverse<STATS>(P, r, tstack, stride, best, bslot, tb, st);
+        } else {
+            for (int k = 0; k < P.n_tris; ++k) {  // brute force, wave-uniform index
+                double t;
+                if (STATS) st.c[9]++;
+                if (tri_hit(P.tris[k], r, t)) consider(t, P.tris[k].id, k, best, bslot, tb);
+            }
+        }
+    }
     t_out = tb;
+    slot_out = bslot;
     return best;
 }
 
@@ -160,17 +273,12 @@ struct Path {
     double2 sq;   // pixel_sets[set][i] (also the glossy lobe sample, brdf.rs:64)
 };
 
-// path statistics (STATS builds only)
-struct Stats {
-    unsigned c[8];
-};
-
 // One Scene::shade level (scene.rs:162-172) for a live lane.  Returns true if
 // the path continues (a bounce was pushed and `p.r` now holds the child ray);
 // otherwise (Lr,Lg,Lb) is the value this level returns.
-template <bool STATS>
+template <bool STATS, bool TRIS>
 __device__ __forceinline__ bool shade_level(const RenderParams &P, Path &p, uint32_t set, uint32_t i,
-                                            double *stk, int stk_stride, double &Lr, double &Lg,
+                                            double *stk, int stk_stride, int *tstack, double &Lr, double &Lg,
                                             double &Lb, Stats &st) {
     if (p.depth > P.max_depth) {  // scene.rs:164-165
         Lr = Lg = Lb = 0.0;
@@ -179,7 +287,8 @@ __device__ __forceinline__ bool shade_level(const RenderParams &P, Path &p, uint
     }
     if (STATS) st.c[1]++;
     double t;
-    const int hit = scene_hit(P, p.r, t);
+    int slot;
+    const int hit = scene_hit<STATS, TRIS>(P, p.r, t, slot, tstack, stk_stride, st);
     if (hit < 0) {  // scene.rs:168
         Lr = P.bgr;
         Lg = P.bgg;
@@ -188,12 +297,15 @@ __device__ __forceinline__ bool shade_level(const RenderParams &P, Path &p, uint
         return false;
     }
     // Hit fields of the winning shape (shapes.rs:140-146,191-197): gathered per lane
-    const DevShape *S = P.shapes + hit;
-    const DevMaterial *M = P.mats + hit;
+    const bool is_tri = TRIS && slot >= 0;
+    const DevShape *S = P.shapes + (is_tri ? 0 : hit);
+    const DevMaterial *M = P.mats + (is_tri ? P.tris[slot].mat : hit);
     const V3 d = mk(p.r.dx, p.r.dy, p.r.dz);
     const V3 pt = mk(p.r.ox + t * d.x, p.r.oy + t * d.y, p.r.oz + t * d.z);
     V3 n;
-    if (S->kind == kShapeSphere) {
+    if (is_tri) {
+        n = mk(P.tris[slot].nx, P.tris[slot].ny, P.tris[slot].nz);
+    } else if (S->kind == kShapeSphere) {
         const double inv = S->inv, rad = S->radius;
         n = mk(((p.r.ox - S->px) + t * d.x) * inv / rad, ((p.r.oy - S->py) + t * d.y) * inv / rad,
                ((p.r.oz - S->pz) + t * d.z) * inv / rad);
@@ -322,7 +434,7 @@ __device__ __forceinline__ void finish_pixel(const RenderParams &P, bool lane_on
 template <bool STATS>
 __device__ __forceinline__ void flush_stats(const RenderParams &P, Stats &st, uint32_t lane) {
     if (!STATS) return;
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < 10; ++c) {
         unsigned v = st.c[c];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         if (lane == 0 && v) atomicAdd(P.stats + c, (unsigned long long)v);
@@ -334,13 +446,14 @@ __device__ __forceinline__ void flush_stats(const RenderParams &P, Stats &st, ui
 // a lane idles from the end of its path until the slowest lane of the chunk is done.
 // Handles every n (also n*n < 64: 64/(n*n) pixels share a wave).
 // ---------------------------------------------------------------------------
-template <bool STATS>
+template <bool STATS, bool TRIS>
 __global__ __launch_bounds__(FLUX_BLOCK_THREADS, FLUX_WAVES_PER_EU) void render_static_kernel(const RenderParams P) {
     extern __shared__ double lds_stack[];
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63;
     const int stride = blockDim.x;
     double *stk = lds_stack + tid;
+    int *tstack = reinterpret_cast<int *>(lds_stack + (size_t)P.max_depth * 4 * stride) + tid;
 
     const uint32_t N = P.nsamp;
     const uint32_t lpp = N >= 64u ? 64u : N;  // lanes per pixel
@@ -375,7 +488,7 @@ __global__ __launch_bounds__(FLUX_BLOCK_THREADS, FLUX_WAVES_PER_EU) void render_
             p.nb = 0;
             if (STATS) st.c[0]++;
             double Lr, Lg, Lb;
-            while (shade_level<STATS>(P, p, set, i, stk, stride, Lr, Lg, Lb, st)) {
+            while (shade_level<STATS, TRIS>(P, p, set, i, stk, stride, tstack, Lr, Lg, Lb, st)) {
             }
             fold_stack(stk, stride, p.nb, Lr, Lg, Lb);
             sr += Lr;  // trace.rs:82
@@ -393,13 +506,14 @@ __global__ __launch_bounds__(FLUX_BLOCK_THREADS, FLUX_WAVES_PER_EU) void render_
 // lanes whose path just ended are compacted (ballot + mbcnt prefix) onto the
 // next unstarted samples.
 // ---------------------------------------------------------------------------
-template <bool STATS>
+template <bool STATS, bool TRIS>
 __global__ __launch_bounds__(FLUX_BLOCK_THREADS, FLUX_WAVES_PER_EU) void render_refill_kernel(const RenderParams P) {
     extern __shared__ double lds_stack[];
     const int tid = threadIdx.x;
     const uint32_t lane = tid & 63;
     const int stride = blockDim.x;
     double *stk = lds_stack + tid;
+    int *tstack = reinterpret_cast<int *>(lds_stack + (size_t)P.max_depth * 4 * stride) + tid;
 
     const uint32_t N = P.nsamp;
     const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (tid >> 6);
@@ -451,7 +565,7 @@ __global__ __launch_bounds__(FLUX_BLOCK_THREADS, FLUX_WAVES_PER_EU) void render_
             // --- one Scene::shade level for every live lane
             if (live) {
                 double Lr, Lg, Lb;
-                if (!shade_level<STATS>(P, p, set, i, stk, stride, Lr, Lg, Lb, st)) {
+                if (!shade_level<STATS, TRIS>(P, p, set, i, stk, stride, tstack, Lr, Lg, Lb, st)) {
                     fold_stack(stk, stride, p.nb, Lr, Lg, Lb);
                     sr += Lr;
                     sg += Lg;
@@ -479,19 +593,23 @@ hipError_t launch_render(const RenderParams &p, int variant, hipStream_t stream)
     const unsigned wpb = block / 64;
     const uint64_t blocks = (waves + wpb - 1) / wpb;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = (size_t)p.max_depth * 4 * block * sizeof(double);
+    const bool tris = p.n_tris > 0;
+    const size_t lds = (size_t)p.max_depth * 4 * block * sizeof(double) +
+                       (tris ? (size_t)p.bvh_stack * block * sizeof(int) : 0);
     const bool stats = p.stats != nullptr;
-    if (variant == FLUX_KERNEL_STATIC) {
-        if (stats)
-            render_static_kernel<true><<<dim3((unsigned)blocks), dim3(block), lds, stream>>>(p);
-        else
-            render_static_kernel<false><<<dim3((unsigned)blocks), dim3(block), lds, stream>>>(p);
-    } else {
-        if (stats)
-            render_refill_kernel<true><<<dim3((unsigned)blocks), dim3(block), lds, stream>>>(p);
-        else
-            render_refill_kernel<false><<<dim3((unsigned)blocks), dim3(block), lds, stream>>>(p);
-    }
+    const dim3 g((unsigned)blocks), b(block);
+#define FLUX_LAUNCH(K)                                                     \
+    do {                                                                   \
+        if (stats && tris) K<true, true><<<g, b, lds, stream>>>(p);        \
+        else if (stats) K<true, false><<<g, b, lds, stream>>>(p);          \
+        else if (tris) K<false, true><<<g, b, lds, stream>>>(p);           \
+        else K<false, false><<<g, b, lds, stream>>>(p);                    \
+    } while (0)
+    if (variant == FLUX_KERNEL_STATIC)
+        FLUX_LAUNCH(render_static_kernel);
+    else
+        FLUX_LAUNCH(render_refill_kernel);
+#undef FLUX_LAUNCH
     return hipGetLastError();
 }
 

@@ -14,7 +14,7 @@ from . import _lib
 from .scene import JobConfiguration, SceneData, SceneDesc, WorkUnit, WorkUnitResult
 
 STAT_NAMES = ("samples", "segments", "matte_bounces", "glossy_bounces", "specular_bounces",
-              "emissive_hits", "misses", "depth_exhausted")
+              "emissive_hits", "misses", "depth_exhausted", "bvh_nodes", "tris_tested")
 
 
 class Renderer:
@@ -89,9 +89,19 @@ class Renderer:
         _lib.check(_lib.lib.flux_ctx_enable_stats(self._handle(), 1 if on else 0))
 
     def stats(self, reset=False) -> dict:
-        buf = (C.c_uint64 * 8)()
+        buf = (C.c_uint64 * _lib.NUM_STATS)()
         _lib.check(_lib.lib.flux_ctx_stats(self._handle(), buf, 1 if reset else 0))
         return dict(zip(STAT_NAMES, [int(x) for x in buf]))
+
+    def set_traversal(self, mode: int):
+        """Extension: 0 = BVH (default), 1 = brute force over the triangles."""
+        _lib.check(_lib.lib.flux_ctx_set_traversal(self._handle(), mode))
+
+    def bvh_info(self) -> dict:
+        buf = (C.c_uint64 * 8)()
+        _lib.check(_lib.lib.flux_ctx_bvh_info(self._handle(), buf))
+        names = ("nodes", "triangles", "max_depth", "max_leaf", "node_bytes", "tri_bytes", "build_us")
+        return dict(zip(names, [int(x) for x in buf]))
 
     def table(self, which: int) -> np.ndarray:
         S = self.width

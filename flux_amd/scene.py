@@ -266,9 +266,25 @@ class SceneDesc:
     """Owns a flux_scene_desc and the buffers it points to."""
 
     def __init__(self, sd: SceneData):
-        n = len(sd.shapes)
+        import ctypes as C
+
+        import numpy as np
+        analytic, meshes = split_shapes(sd)
+        n = len(analytic)
         self.shapes = (_lib.FluxShape * max(n, 1))()
-        for i, s in enumerate(sd.shapes):
+        self.meshes = (_lib.FluxMesh * max(len(meshes), 1))()
+        self._mesh_bufs = []
+        for i, m in enumerate(meshes):
+            v = np.ascontiguousarray(m.vertices, dtype=np.float64).reshape(-1, 3)
+            t = np.ascontiguousarray(m.triangles, dtype=np.uint32).reshape(-1, 3)
+            self._mesh_bufs.append((v, t))
+            fm = self.meshes[i]
+            fm.num_vertices = len(v)
+            fm.vertices = v.ctypes.data_as(C.POINTER(C.c_double))
+            fm.num_triangles = len(t)
+            fm.indices = t.ctypes.data_as(C.POINTER(C.c_uint32))
+            fm.material = material_to_abi(m.material)
+        for i, s in enumerate(analytic):
             fs = self.shapes[i]
             if isinstance(s, SphereData):
                 fs.kind = _lib.SHAPE_SPHERE
@@ -298,4 +314,55 @@ class SceneDesc:
         d.lens_radius = sd.camera_data.lens_radius
         d.num_shapes = n
         d.shapes = self.shapes
+        d.num_meshes = len(meshes)
+        d.meshes = self.meshes
         self.desc = d
+
+
+# ---- extension: triangle meshes (absent in the reference, scene.rs:71-74) ------------------------
+
+@dataclass
+class MeshData:
+    """Indexed triangle mesh.  YAML (extension of the ShapeData enum):
+        - Mesh: {vertices: [[x,y,z], ...], triangles: [[i,j,k], ...], material: {...}}
+        - Triangle: {v0: [..], v1: [..], v2: [..], material: {...}}      (a one-triangle mesh)
+    Hit order: all Sphere/Plane shapes first (YAML order), then mesh triangles in YAML/index order."""
+    vertices: object  # float64 ndarray [nv][3]
+    triangles: object  # uint32 ndarray [nt][3]
+    material: MaterialData
+
+
+def mesh_from_yaml(tag, b, what):
+    import numpy as np
+    w = f"{what}.{tag}"
+    mat = material_from_yaml(_req(b, "material", w), w + ".material")
+    if tag == "Triangle":
+        v = np.array([_vec3(_req(b, k, w), f"{w}.{k}") for k in ("v0", "v1", "v2")], dtype=np.float64)
+        return MeshData(v, np.array([[0, 1, 2]], dtype=np.uint32), mat)
+    verts = _req(b, "vertices", w)
+    tris = _req(b, "triangles", w)
+    try:
+        v = np.array(verts, dtype=np.float64).reshape(-1, 3)
+        t = np.array(tris, dtype=np.int64).reshape(-1, 3)
+    except (ValueError, TypeError):
+        raise SceneError(f"{w}: vertices must be [[x,y,z],...] and triangles [[i,j,k],...]")
+    if t.size and (t.min() < 0 or t.max() >= len(v)):
+        raise SceneError(f"{w}: triangle index out of range (have {len(v)} vertices)")
+    return MeshData(v, t.astype(np.uint32), mat)
+
+
+_shape_from_yaml_reference = shape_from_yaml
+
+
+def shape_from_yaml(m, what="shape"):  # noqa: F811  (extends the reference enum with Mesh / Triangle)
+    tag, b = _single_variant(m, what)
+    if tag in ("Mesh", "Triangle"):
+        return mesh_from_yaml(tag, b, what)
+    return _shape_from_yaml_reference(m, what)
+
+
+def split_shapes(sd: SceneData):
+    """(analytic shapes in order, meshes in order) -- the hit order of include/flux_abi.h."""
+    analytic = [s for s in sd.shapes if not isinstance(s, MeshData)]
+    meshes = [s for s in sd.shapes if isinstance(s, MeshData)]
+    return analytic, meshes

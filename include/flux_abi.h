@@ -75,6 +75,20 @@ typedef struct flux_shape {
     flux_material material;
 } flux_shape;
 
+/* EXTENSION (absent in the reference: scene.rs:71-74 has Sphere | Plane only, TODO.md lists a Quad):
+ * an indexed triangle mesh.  Semantics chosen to follow the reference's conventions for Plane
+ * (shapes.rs:135-152): two-sided, hit iff t > T_MIN, geometric normal normalize((v1-v0) x (v2-v0))
+ * stored per triangle and never flipped towards the ray.  Intersection is Moeller-Trumbore in f64
+ * (DESIGN.md "Triangles and the BVH").  Hit order for the nearest-hit tie rule: all `shapes` first
+ * (YAML order), then the triangles of meshes[0], meshes[1], ... in index order. */
+typedef struct flux_mesh {
+    uint64_t num_vertices;
+    const double *vertices;  /* [num_vertices][3] */
+    uint64_t num_triangles;
+    const uint32_t *indices; /* [num_triangles][3] vertex indices */
+    flux_material material;
+} flux_mesh;
+
 /* SceneData (scene.rs:40-49) with CameraSettings (:14-18), CameraData
  * (:53-58) and OutputSettings (:62-66) inlined.  `shapes` keeps YAML order:
  * Scene::hit resolves distance ties to the lowest index (scene.rs:156-160,
@@ -94,6 +108,8 @@ typedef struct flux_scene_desc {
     double lens_radius;
     uint64_t num_shapes;
     const flux_shape *shapes;
+    uint64_t num_meshes;      /* extension; 0 for reference scenes */
+    const flux_mesh *meshes;
 } flux_scene_desc;
 
 /* JobConfiguration: fluxcore/src/job.rs:49-53 */
@@ -155,6 +171,12 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
 #define FLUX_KERNEL_REFILL 2
 int flux_ctx_set_kernel(flux_ctx *ctx, int variant);
 
+/* Triangle traversal (extension): 0 = BVH with a per-lane LDS stack (default), 1 = brute force over
+ * all triangles in index order (the definition the BVH must reproduce exactly; parity tests). */
+#define FLUX_TRAVERSE_BVH 0
+#define FLUX_TRAVERSE_BRUTE 1
+int flux_ctx_set_traversal(flux_ctx *ctx, int mode);
+
 /* Device time (ms, HIP events on the launch stream) of the most recent render
  * kernel launched through this context; synchronises that launch. <0 on error. */
 double flux_ctx_last_kernel_ms(flux_ctx *ctx);
@@ -163,9 +185,15 @@ double flux_ctx_last_kernel_ms(flux_ctx *ctx);
  * flux_ctx_enable_stats(ctx,1) before rendering; off by default):
  * [0] samples, [1] ray segments, [2] Matte bounces, [3] glossy bounces,
  * [4] perfect-specular bounces, [5] emissive terminations, [6] misses,
- * [7] depth-exhausted paths. */
+ * [7] depth-exhausted paths, [8] BVH nodes visited, [9] triangles tested,
+ * [10..15] reserved (0). */
+#define FLUX_NUM_STATS 16
 int flux_ctx_enable_stats(flux_ctx *ctx, int on);
-int flux_ctx_stats(flux_ctx *ctx, uint64_t out[8], int reset);
+int flux_ctx_stats(flux_ctx *ctx, uint64_t out[FLUX_NUM_STATS], int reset);
+
+/* BVH introspection (extension): out[0] nodes, [1] triangles, [2] max depth, [3] max leaf size,
+ * [4] node bytes, [5] triangle-record bytes, [6] build microseconds, [7] reserved. */
+int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t out[8]);
 
 /* Introspection used by the parity tests (device -> host copies).
  * which: 0 = pixel_sets [S][N][2], 1 = disc_sets [S][N][2],

@@ -353,6 +353,13 @@ typedef struct {
     material mat;
 } shape;
 
+/* EXTENSION (no reference counterpart; scene.rs:71-74 is Sphere | Plane only): triangle with the
+ * conventions of Plane (shapes.rs:135-152) -- two-sided, t > T_MIN, stored geometric normal. */
+typedef struct {
+    v3 v0, e1, e2, normal;
+    material mat;
+} triangle;
+
 typedef struct { v3 origin, direction; } ray;
 
 /* Hit: common.rs:7-14 */
@@ -375,6 +382,8 @@ struct fxo_ctx {
     rgb background;
     int num_shapes;
     shape *shapes;
+    size_t num_tris, cap_tris; /* extension: triangles follow the shapes in hit order */
+    triangle *tris;
     /* CameraBasis: scene.rs:22-35 */
     v3 u, v, w;
     /* JobConfiguration: job.rs:49-53 */
@@ -486,6 +495,32 @@ static int sphere_hit(const shape *s, const ray *r, int depth, hit *h) {
     return 0;
 }
 
+/* EXTENSION: Moeller-Trumbore, f64, no culling.  The product's BVH traversal must return exactly
+ * what this brute-force definition returns (DESIGN.md "Triangles and the BVH"). */
+static int triangle_hit(const triangle *tr, const ray *r, int depth, hit *h) {
+    v3 p = v3_cross(r->direction, tr->e2);
+    double det = v3_dot(tr->e1, p);
+    if (det == 0.0) return 0;
+    double inv = 1.0 / det;
+    v3 s = v3_sub(r->origin, tr->v0);
+    double u = v3_dot(s, p) * inv;
+    if (u < 0.0 || u > 1.0) return 0;
+    v3 q = v3_cross(s, tr->e1);
+    double v = v3_dot(r->direction, q) * inv;
+    if (v < 0.0 || u + v > 1.0) return 0;
+    double t = v3_dot(tr->e2, q) * inv;
+    if (t > T_MIN) {
+        h->r = *r;
+        h->depth = depth;
+        h->distance = t;
+        h->normal = tr->normal;
+        h->local_hit_point = v3_add(r->origin, v3_scale(r->direction, t));
+        h->mat = &tr->mat;
+        return 1;
+    }
+    return 0;
+}
+
 /* Scene::hit: scene.rs:156-160 with Hit::compare (common.rs:17-23) under
  * Iterator::min_by: the accumulated minimum is replaced only when
  * compare(acc,new) == Greater, i.e. when !(acc.distance <= new.distance);
@@ -498,6 +533,18 @@ static int scene_hit(const fxo_ctx *c, const ray *r, int depth, hit *best) {
                                                        : plane_hit(&c->shapes[i], r, depth, &h);
         if (!ok) continue;
         h.shape_index = i;
+        if (!found) {
+            *best = h;
+            found = 1;
+        } else if (!(best->distance <= h.distance)) {
+            *best = h;
+        }
+    }
+    /* extension: triangles continue the same ordered scan (indices num_shapes + k) */
+    for (size_t k = 0; k < c->num_tris; k++) {
+        hit h;
+        if (!triangle_hit(&c->tris[k], r, depth, &h)) continue;
+        h.shape_index = c->num_shapes + (int)k;
         if (!found) {
             *best = h;
             found = 1;
@@ -820,8 +867,37 @@ fxo_ctx *fxo_ctx_create(const double *camera, int image_width, int image_height,
     return c;
 }
 
+int fxo_ctx_add_mesh(fxo_ctx *c, const double *vertices, size_t num_vertices, const uint32_t *indices,
+                     size_t num_triangles, int mat_kind, const double *mat_params) {
+    if (!c || (num_triangles && (!vertices || !indices))) return -1;
+    for (size_t k = 0; k < 3 * num_triangles; k++)
+        if (indices[k] >= num_vertices) return -1;
+    if (c->num_tris + num_triangles > c->cap_tris) {
+        size_t cap = (c->num_tris + num_triangles) * 2;
+        triangle *t = realloc(c->tris, cap * sizeof(triangle));
+        if (!t) return -1;
+        c->tris = t;
+        c->cap_tris = cap;
+    }
+    for (size_t k = 0; k < num_triangles; k++) {
+        triangle *t = &c->tris[c->num_tris + k];
+        const double *a = vertices + 3 * (size_t)indices[3 * k];
+        const double *b = vertices + 3 * (size_t)indices[3 * k + 1];
+        const double *d = vertices + 3 * (size_t)indices[3 * k + 2];
+        t->v0 = v3_new(a[0], a[1], a[2]);
+        t->e1 = v3_sub(v3_new(b[0], b[1], b[2]), t->v0);
+        t->e2 = v3_sub(v3_new(d[0], d[1], d[2]), t->v0);
+        t->normal = v3_normalize(v3_cross(t->e1, t->e2));
+        t->mat.kind = mat_kind;
+        memcpy(t->mat.p, mat_params, 8 * sizeof(double));
+    }
+    c->num_tris += num_triangles;
+    return 0;
+}
+
 void fxo_ctx_destroy(fxo_ctx *c) {
     if (!c) return;
+    free(c->tris);
     free(c->shapes);
     free(c->pixel_sets);
     free(c->disc_sets);

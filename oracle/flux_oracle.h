@@ -55,6 +55,10 @@ fxo_ctx *fxo_ctx_create(const double *camera, int image_width, int image_height,
                         const double *mat_params, int sample_root,
                         int max_trace_depth, uint64_t seed);
 void fxo_ctx_destroy(fxo_ctx *c);
+/* EXTENSION (triangles do not exist in the reference): append an indexed mesh; its triangles follow
+ * all shapes (and earlier meshes) in hit order and are intersected by brute force. Returns 0/-1. */
+int fxo_ctx_add_mesh(fxo_ctx *c, const double *vertices, size_t num_vertices, const uint32_t *indices,
+                     size_t num_triangles, int mat_kind, const double *mat_params);
 
 /* Camera::render (trace.rs:53-97) for rows [row_start,row_end] inclusive.
  * out: (row_end-row_start+1)*W*3 f64, averaged and max_to_one-clamped.

@@ -37,6 +37,7 @@ def _load():
     lib.fxo_ctx_create.argtypes = [_dp, C.c_int, C.c_int, C.c_double, _dp, C.c_int, _ip, _dp, _ip, _dp, C.c_int,
                                    C.c_int, C.c_uint64]
     lib.fxo_ctx_destroy.argtypes = [C.c_void_p]
+    lib.fxo_ctx_add_mesh.argtypes = [C.c_void_p, _dp, C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t, C.c_int, _dp]
     lib.fxo_render_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, _dp, C.c_int]
     lib.fxo_render_row_list.argtypes = [C.c_void_p, _ip, C.c_size_t, _dp, C.c_int]
     lib.fxo_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -121,8 +122,11 @@ class Oracle:
             sd.camera_data.zoom_factor, sd.camera_data.view_plane_distance, sd.camera_data.focal_distance,
             sd.camera_data.lens_radius]
         kinds, sp, mk, mp = [], [], [], []
+        meshes = [s for s in sd.shapes if type(s).__name__ == "MeshData"]
         for s in sd.shapes:
             p = [0.0] * 8
+            if type(s).__name__ == "MeshData":
+                continue  # extension: appended after all analytic shapes, see below
             if type(s).__name__ == "SphereData":
                 kinds.append(SHAPE_SPHERE)
                 p[0:3] = s.center
@@ -154,6 +158,15 @@ class Oracle:
                                      self.D, C.c_uint64(seed))
         if not self._h:
             raise ValueError("fxo_ctx_create failed (bad arguments)")
+        for m in meshes:  # extension (no reference counterpart): brute-force triangles
+            v = np.ascontiguousarray(m.vertices, dtype=np.float64).reshape(-1, 3)
+            t = np.ascontiguousarray(m.triangles, dtype=np.uint32).reshape(-1, 3)
+            k, q = material_params(m.material)
+            q_a, q_p = _d(q)
+            rc = lib.fxo_ctx_add_mesh(self._h, v.ctypes.data_as(_dp), len(v), t.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      len(t), k, q_p)
+            if rc != 0:
+                raise ValueError("fxo_ctx_add_mesh failed")
 
     def close(self):
         if getattr(self, "_h", None):

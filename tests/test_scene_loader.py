@@ -48,8 +48,8 @@ def test_missing_field_is_an_error(flux):
 
 def test_unknown_variant_is_an_error(flux):
     d = _doc()
-    d["shapes"][0] = {"Triangle": {}}
-    with pytest.raises(flux.SceneError, match="unknown variant `Triangle`"):
+    d["shapes"][0] = {"Torus": {}}
+    with pytest.raises(flux.SceneError, match="unknown variant `Torus`"):
         flux.scene_from_dict(d)
     d = _doc()
     d["shapes"][1]["Sphere"]["material"] = {"Glass": {}}

@@ -1,0 +1,142 @@
+"""Extension: triangle meshes + BVH (absent in the reference: scene.rs:71-74 is Sphere | Plane only, so there
+is no reference oracle).  The definition is the brute-force scan in the CPU oracle (Moeller-Trumbore f64,
+Plane's conventions); the GPU's BVH traversal must return exactly the brute-force nearest hit."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import max_abs_diff, small_scene
+
+
+def _tri_scene(flux, demo2, meshes, w=32, h=24):
+    sd = copy.deepcopy(small_scene(demo2, w, h))
+    sd.shapes = list(sd.shapes) + list(meshes)
+    return sd
+
+
+def _one(flux, v0, v1, v2, mat=None):
+    from flux_amd.scene import MeshData
+    mat = mat or flux.EmissiveData((1.0, 0.5, 0.25), 2.0)
+    return MeshData(np.array([v0, v1, v2], dtype=np.float64), np.array([[0, 1, 2]], dtype=np.uint32), mat)
+
+
+# ------------------------------------------------------------------ oracle KATs (CPU)
+def test_triangle_hit_kat(flux, oracle_mod, demo2):
+    """Hand-derived: unit right triangle in the z=0 plane, ray along +z from (0.25,0.25,-2): t = 2,
+    normal = normalize(e1 x e2) = (0,0,1) (never flipped), two-sided, t > T_MIN, edges inclusive."""
+    sd = copy.deepcopy(small_scene(demo2, 8, 6))
+    sd.shapes = [_one(flux, (0, 0, 0), (1, 0, 0), (0, 1, 0))]
+    o = oracle_mod.Oracle(sd, flux.JobConfiguration(1, 5, 50))
+    idx, t, n, p = o.scene_hit((0.25, 0.25, -2.0), (0, 0, 1))
+    assert idx == 0 and t == 2.0 and np.array_equal(n, [0, 0, 1]) and np.array_equal(p, [0.25, 0.25, 0.0])
+    idx, t, n, _ = o.scene_hit((0.25, 0.25, 2.0), (0, 0, -1))          # from the back: same stored normal
+    assert idx == 0 and t == 2.0 and np.array_equal(n, [0, 0, 1])
+    assert o.scene_hit((0.75, 0.75, -2.0), (0, 0, 1))[0] == -1           # u+v > 1
+    assert o.scene_hit((-0.1, 0.5, -2.0), (0, 0, 1))[0] == -1            # u < 0
+    assert o.scene_hit((0.5, 0.0, -2.0), (0, 0, 1))[0] == 0              # on an edge: inclusive
+    assert o.scene_hit((0.25, 0.25, -2.0), (1, 0, 0))[0] == -1           # parallel: det == 0
+    assert o.scene_hit((0.25, 0.25, 1.0), (0, 0, 1))[0] == -1            # behind
+    assert o.scene_hit((0.25, 0.25, -0.0004), (0, 0, 1))[0] == -1        # t <= T_MIN
+    # emissive triangle emits towards +z side only (materials.rs:41-50 with the stored normal)
+    assert np.array_equal(o.shade((0.25, 0.25, 2.0), (0, 0, -1), 1, 0, 0), [2.0, 1.0, 0.5])
+    assert np.array_equal(o.shade((0.25, 0.25, -2.0), (0, 0, 1), 1, 0, 0), [0, 0, 0])
+
+
+def test_triangle_order_and_ties(flux, oracle_mod, demo2):
+    """Shapes precede triangles in hit order; coincident triangles resolve to the lower index."""
+    sd = copy.deepcopy(small_scene(demo2, 8, 6))
+    a = _one(flux, (0, 0, 0), (1, 0, 0), (0, 1, 0), flux.EmissiveData((1, 0, 0), 1.0))
+    b = _one(flux, (0, 0, 0), (1, 0, 0), (0, 1, 0), flux.EmissiveData((0, 1, 0), 1.0))
+    pl = flux.PlaneData((0, 0, 0), (0, 0, 1), flux.EmissiveData((0, 0, 1), 1.0))
+    sd.shapes = [a, b]
+    o = oracle_mod.Oracle(sd, flux.JobConfiguration(1, 5, 50))
+    assert o.scene_hit((0.25, 0.25, 2.0), (0, 0, -1))[0] == 0
+    sd.shapes = [a, pl, b]  # the plane is an analytic shape: index 0, triangles follow as 1, 2
+    o = oracle_mod.Oracle(sd, flux.JobConfiguration(1, 5, 50))
+    assert o.scene_hit((0.25, 0.25, 2.0), (0, 0, -1))[0] == 0
+    assert np.array_equal(o.shade((0.25, 0.25, 2.0), (0, 0, -1), 1, 0, 0), [0, 0, 1])
+
+
+def test_yaml_mesh_and_triangle(flux):
+    import yaml
+    doc = yaml.safe_load(open(__import__("os").path.join(__import__("conftest").SCENES, "demo1.yml")))
+    doc["shapes"].append({"Triangle": {"v0": [0, 0, 0], "v1": [1, 0, 0], "v2": [0, 1, 0],
+                                       "material": {"Emissive": {"color": [1, 1, 1], "power": 1.0}}}})
+    doc["shapes"].append({"Mesh": {"vertices": [[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]],
+                                   "triangles": [[0, 1, 2], [1, 3, 2]],
+                                   "material": {"Matte": {"diffuse_color": [1, 1, 1], "ambient_color": [1, 1, 1],
+                                                          "diffuse_coefficient": 1.0}}}})
+    sd = flux.scene_from_dict(doc)
+    from flux_amd.scene import MeshData, SceneDesc
+    assert isinstance(sd.shapes[-1], MeshData) and sd.shapes[-1].triangles.shape == (2, 3)
+    d = SceneDesc(sd)
+    assert d.desc.num_shapes == 6 and d.desc.num_meshes == 2 and d.meshes[1].num_triangles == 2
+    doc["shapes"][-1]["Mesh"]["triangles"] = [[0, 1, 9]]
+    with pytest.raises(flux.SceneError):
+        flux.scene_from_dict(doc)
+
+
+def test_heightfield_generator(flux):
+    from flux_amd.procedural import heightfield_mesh, heightfield_scene
+    m = heightfield_mesh(10, 5, seed=1)
+    assert m.vertices.shape == (11 * 6, 3) and m.triangles.shape == (100, 3)
+    assert np.array_equal(m.triangles[0], [0, 1, 7]) and np.array_equal(m.triangles[1], [0, 7, 6])
+    assert abs(m.vertices[:, 1]).max() <= 0.37
+    m2 = heightfield_mesh(10, 5, seed=1)
+    assert np.array_equal(m.vertices, m2.vertices)
+    sd = heightfield_scene(4, 4)
+    assert len(sd.shapes) == 14 and sd.shapes[-1].triangles.shape == (32, 3)
+
+
+# ------------------------------------------------------------------ GPU parity
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,nz", [(1, 1), (3, 2), (24, 16), (60, 40)])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_bvh_equals_bruteforce_equals_oracle(flux, oracle_mod, demo2, nx, nz, variant):
+    from flux_amd.procedural import heightfield_scene
+    sd = heightfield_scene(nx, nz, seed=7, base=small_scene(demo2, 48, 36))
+    cfg = flux.JobConfiguration(8, 5, 50)
+    with flux.Renderer(sd, cfg, seed=3) as r:
+        r.set_kernel(variant)
+        info = r.bvh_info()
+        assert info["triangles"] == 2 * nx * nz and info["max_leaf"] <= 4 and info["max_depth"] <= 64
+        bvh = r.render_frame()
+        r.set_traversal(flux._lib.TRAVERSE_BRUTE)
+        brute = r.render_frame()
+        assert np.array_equal(bvh, brute)          # the BVH returns exactly the brute-force hits
+    if nx * nz <= 24 * 16:
+        want = oracle_mod.Oracle(sd, cfg, seed=3).render_frame(threads=8)
+        assert max_abs_diff(bvh, want) < 1e-4
+        assert np.percentile(np.abs(bvh - want), 99.9) < 1e-9
+
+
+@pytest.mark.gpu
+def test_bvh_stats_and_degenerate_meshes(flux, oracle_mod, demo2):
+    from flux_amd.procedural import heightfield_scene
+    from flux_amd.scene import MeshData
+    sd = heightfield_scene(40, 30, seed=2, base=small_scene(demo2, 32, 24))
+    with flux.Renderer(sd, flux.JobConfiguration(8, 5, 50), seed=1) as r:
+        r.enable_stats(True)
+        r.stats(reset=True)
+        a = r.render_frame()
+        st = r.stats(reset=True)
+        assert st["bvh_nodes"] > 0 and 0 < st["tris_tested"] < st["segments"] * 2400 // 20
+        r.set_traversal(flux._lib.TRAVERSE_BRUTE)
+        b = r.render_frame()
+        st2 = r.stats()
+        assert st2["tris_tested"] == st2["segments"] * 2400 and st2["bvh_nodes"] == 0
+        for k in ("samples", "segments", "matte_bounces", "glossy_bounces", "emissive_hits"):
+            assert st[k] == st2[k]
+        assert np.array_equal(a, b)
+    # many coincident + zero-area triangles: ties resolve to the lowest index, degenerate ones never hit
+    v = np.array([[0, 0.5, 0], [2, 0.5, 0], [0, 0.5, 2], [1, 0.5, 1]], dtype=np.float64)
+    t = np.array([[0, 1, 2]] * 40 + [[0, 3, 3]] * 10 + [[0, 2, 1]] * 7, dtype=np.uint32)
+    sd2 = copy.deepcopy(small_scene(demo2, 32, 24))
+    sd2.shapes = list(sd2.shapes) + [MeshData(v, t, flux.EmissiveData((0.2, 1.0, 0.1), 3.0))]
+    cfg = flux.JobConfiguration(4, 5, 50)
+    with flux.Renderer(sd2, cfg, seed=1) as r:
+        a = r.render_frame()
+        r.set_traversal(flux._lib.TRAVERSE_BRUTE)
+        assert np.array_equal(a, r.render_frame())
+    assert max_abs_diff(a, oracle_mod.Oracle(sd2, cfg, seed=1).render_frame(threads=4)) < 1e-4
