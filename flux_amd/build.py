@@ -57,5 +57,30 @@ def build_hip(force=False, verbose=False):
     return HIP_LIB
 
 
+HOST_DIR = os.path.join(ROOT, "flux_amd", "host")
+HOST_SOURCES = ["flux_host.cpp", "yaml_lite.cpp"]
+HOST_BINARIES = {"flux": "flux_cli.cpp", "flux_host_test": "flux_host_test.cpp"}
+
+
+def build_host(force=False, verbose=False):
+    """C++ host layer above the C ABI: the flag-compatible `flux` CLI and its CPU-only self test."""
+    build_hip(force=False, verbose=verbose)
+    outs = []
+    common = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
+    hdrs = [os.path.join(HOST_DIR, h) for h in ("flux_host.hpp", "yaml_lite.hpp")] + [os.path.join(ROOT, "include", "flux_abi.h")]
+    for name, main in HOST_BINARIES.items():
+        out = os.path.join(HOST_DIR, name)
+        src = [os.path.join(HOST_DIR, main)] + common
+        if force or _newer(out, src + hdrs + [HIP_LIB]):
+            cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-o", out] + src + [
+                "-L" + os.path.join(ROOT, "flux_amd"), "-lflux_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+        outs.append(out)
+    return outs
+
+
 if __name__ == "__main__":
     print(build_hip(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

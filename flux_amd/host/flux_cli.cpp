@@ -1,0 +1,174 @@
+// flux_cli.cpp -- flag-compatible `flux` front-end driving GpuWorkers.
+//
+// Mirrors flux/src/main.rs: config_from_args (:126-205; same flags, same defaults: root 1, depth 5,
+// 50 rows per work unit), load YAML -> SceneData (:27-29), start workers (:37-70), schedule one job and
+// wait (:92-94), ImageBuilder writes "<scene_name>.ppm" into the cwd and prints the total time
+// (manager.rs:326-335).  Additions: --seed (the reference seeds from OS entropy), --gpus, --outdir.
+// Not carried over: -n/--node (CBOR/TCP render nodes) and -g (SDL preview) -- out of scope, rejected.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "flux_host.hpp"
+
+using namespace flux_host;
+
+namespace {
+
+const size_t DEFAULT_SAMPLE_ROOT = 1;  // flux/src/main.rs:20
+const size_t DEFAULT_DEPTH = 5;        // flux/src/main.rs:21
+
+struct Config {  // flux/src/main.rs:115-124
+    std::vector<std::string> network_workers;
+    bool use_local_worker = true;
+    size_t sample_root = DEFAULT_SAMPLE_ROOT;
+    size_t max_depth = DEFAULT_DEPTH;
+    size_t rows_per_work_unit = 50;
+    std::string input_filename;
+    bool show_live_preview = false;
+    size_t num_threads = 0;
+    // additions
+    uint64_t seed = 1;
+    int gpus = -1;
+    std::string outdir = ".";
+};
+
+void usage() {
+    std::fprintf(stderr,
+                 "flux (MI355X render path)\n\nUSAGE:\n    flux [FLAGS] [OPTIONS] <scene_file>\n\nFLAGS:\n"
+                 "    -L               Do not use the local host for rendering (accepted; there is no CPU worker)\n"
+                 "    -g               Show a live graphical preview window during rendering (not supported)\n\nOPTIONS:\n"
+                 "    -d, --depth <DEPTH>          Tracing depth [default 5]\n"
+                 "    -n, --node <ADDRESS[:PORT]>  Render using a flux-node process (not supported)\n"
+                 "    -R, --rows <COUNT>           Image rows per work unit [default 50]\n"
+                 "    -r, --root <ROOT>            Sample root [default 1]\n"
+                 "    -t, --threads <N>            CPU rendering threads (accepted, unused)\n"
+                 "        --seed <SEED>            RNG seed [default 1]\n"
+                 "        --gpus <N>               number of GPUs to use [default: all]\n"
+                 "        --outdir <DIR>           where <scene_name>.ppm is written [default .]\n");
+}
+
+size_t parse_usize(const char *flag, const char *v) {
+    char *end = nullptr;
+    unsigned long long x = std::strtoull(v, &end, 10);
+    if (end == v || *end != '\0' || v[0] == '-') {
+        // usize::from_str(..).unwrap() panics in the reference
+        std::fprintf(stderr, "error: invalid value '%s' for '%s'\n", v, flag);
+        std::exit(2);
+    }
+    return (size_t)x;
+}
+
+Config config_from_args(int argc, char **argv) {
+    Config c;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto need = [&](const char *flag) -> const char * {
+            if (i + 1 >= argc) {
+                std::fprintf(stderr, "error: The argument '%s' requires a value\n", flag);
+                std::exit(2);
+            }
+            return argv[++i];
+        };
+        if (a == "-h" || a == "--help") {
+            usage();
+            std::exit(0);
+        } else if (a == "-d" || a == "--depth") {
+            c.max_depth = parse_usize("--depth", need("--depth"));
+        } else if (a == "-R" || a == "--rows") {
+            c.rows_per_work_unit = parse_usize("--rows", need("--rows"));
+        } else if (a == "-r" || a == "--root") {
+            c.sample_root = parse_usize("--root", need("--root"));
+        } else if (a == "-t" || a == "--threads") {
+            c.num_threads = parse_usize("--threads", need("--threads"));
+        } else if (a == "-n" || a == "--node") {
+            c.network_workers.push_back(need("--node"));
+        } else if (a == "-L") {
+            c.use_local_worker = false;
+        } else if (a == "-g") {
+            c.show_live_preview = true;
+        } else if (a == "--seed") {
+            c.seed = (uint64_t)parse_usize("--seed", need("--seed"));
+        } else if (a == "--gpus") {
+            c.gpus = (int)parse_usize("--gpus", need("--gpus"));
+        } else if (a == "--outdir") {
+            c.outdir = need("--outdir");
+        } else if (!a.empty() && a[0] == '-') {
+            std::fprintf(stderr, "error: Found argument '%s' which wasn't expected\n", a.c_str());
+            std::exit(2);
+        } else if (c.input_filename.empty()) {
+            c.input_filename = a;
+        } else {
+            std::fprintf(stderr, "error: Found argument '%s' which wasn't expected\n", a.c_str());
+            std::exit(2);
+        }
+    }
+    if (c.input_filename.empty()) {
+        std::fprintf(stderr, "error: The following required arguments were not provided:\n    <scene_file>\n");
+        usage();
+        std::exit(2);
+    }
+    return c;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    Config config = config_from_args(argc, argv);
+    if (!config.network_workers.empty()) {
+        std::fprintf(stderr, "error: -n/--node: network render nodes are not part of the MI355X render path\n");
+        return 2;
+    }
+    if (config.show_live_preview) {
+        std::fprintf(stderr, "error: -g: the SDL live preview is not part of the MI355X render path\n");
+        return 2;
+    }
+    SceneData s;
+    try {
+        s = scene_from_yaml_file(config.input_filename);
+    } catch (const FluxError &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    int ndev = flux_device_count();
+    if (ndev < 1) {
+        std::fprintf(stderr, "error: no HIP device visible (this renderer has no CPU fallback)\n");
+        return 1;
+    }
+    if (config.gpus > 0 && config.gpus < ndev) ndev = config.gpus;
+
+    std::vector<std::unique_ptr<GpuWorker>> workers;
+    std::vector<WorkerHandle> handles;
+    for (int d = 0; d < ndev; d++) {
+        workers.emplace_back(new GpuWorker(d, config.seed));
+        handles.push_back(workers.back()->handle());
+    }
+    std::printf("Rendering %s with %d GPU worker(s), sample root %zu, depth %zu, %zu rows per work unit\n",
+                s.scene_name.c_str(), ndev, config.sample_root, config.max_depth, config.rows_per_work_unit);
+
+    ImageBuilder image_builder;
+    image_builder.output_dir = config.outdir;
+    Job job;
+    job.id = JobID{0, 0};
+    job.scene_data = s;
+    job.config = JobConfiguration{config.sample_root, config.max_depth, config.rows_per_work_unit};
+    int rc = 0;
+    try {
+        run_job(job, handles, image_builder.sender());
+    } catch (const FluxError &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        rc = 1;
+    }
+    image_builder.stop();
+    for (auto &w : workers) w->stop();
+    if (rc == 0 && !image_builder.written_path.empty()) {
+        const double samples = (double)s.output_settings.image_width * s.output_settings.image_height *
+                               config.sample_root * config.sample_root;
+        std::printf("wrote %s (%.1f Msamples/s incl. context creation)\n", image_builder.written_path.c_str(),
+                    image_builder.total_time_s > 0 ? samples / image_builder.total_time_s / 1e6 : 0.0);
+    }
+    return rc;
+}

@@ -1,0 +1,208 @@
+// flux_host.hpp -- C++ host side above the C ABI, mirroring the reference's plain-data types and
+// its worker interface (same names, same argument meaning), so a GPU sits where a LocalWorker does:
+//
+//   SceneData & friends        fluxcore/src/scene.rs:12-74, shapes.rs:15-81, color.rs:8-16
+//   JobConfiguration, WorkUnit, Job::work_units      fluxcore/src/job.rs:40-88
+//   RenderEvent, WorkUnitResult, WorkerInfo, trait Worker, WorkerHandle
+//                                                    fluxcore/src/manager.rs:16-52,221-236
+//   LocalWorker job loop -> GpuWorker                fluxcore/src/workers.rs:26-103
+//   ImageBuilder, Image::write                       fluxcore/src/manager.rs:278-363, image.rs:43-61
+//
+// The reference is Rust; this image has no Rust toolchain, so the mirror is C++ (std::thread and a
+// small channel instead of crossbeam).  All rendering goes through include/flux_abi.h.
+#pragma once
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <variant>
+#include <vector>
+
+#include "../../include/flux_abi.h"
+
+namespace flux_host {
+
+struct FluxError : std::runtime_error {
+    int code;
+    FluxError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+// ---- scene description (serde schema of the reference) ---------------------------------------
+struct Color { double r = 0, g = 0, b = 0; };
+struct Vec3 { double x = 0, y = 0, z = 0; };
+
+struct MatteData { Color diffuse_color, ambient_color; double diffuse_coefficient = 0; };
+struct EmissiveData { Color color; double power = 0; };
+struct ReflectiveData { double reflect_amount = 0; Color reflect_color; };
+struct GlossyReflectiveData { double reflect_amount = 0; Color reflect_color; double reflect_exponent = 0; };
+using MaterialData = std::variant<MatteData, EmissiveData, ReflectiveData, GlossyReflectiveData>;
+
+struct SphereData { Vec3 center; double radius = 0; MaterialData material; bool invert = false; };
+struct PlaneData { Vec3 point, normal; MaterialData material; };
+using ShapeData = std::variant<SphereData, PlaneData>;
+
+struct CameraSettings { Vec3 eye, look_at, up; };
+struct CameraData { double zoom_factor = 1, view_plane_distance = 0, focal_distance = 0, lens_radius = 0; };
+struct OutputSettings { size_t image_width = 0, image_height = 0; double pixel_size = 0; };
+
+struct SceneData {
+    std::string scene_name;
+    OutputSettings output_settings;
+    Color background;
+    std::vector<ShapeData> shapes;
+    CameraSettings camera_settings;
+    CameraData camera_data;
+};
+
+// serde_yaml::from_reader (flux/src/main.rs:27-29); throws FluxError(FLUX_E_INVALID) with a
+// serde-style message on missing fields / unknown variants.
+SceneData scene_from_yaml_file(const std::string &path);
+SceneData scene_from_yaml_text(const std::string &text);
+
+// ---- jobs ---------------------------------------------------------------------------------------
+struct JobID { size_t allocator_id = 0, id = 0; };
+struct JobConfiguration { size_t sample_root = 1, max_trace_depth = 5, rows_per_work_unit = 50; };
+struct WorkUnit { size_t row_start = 0, row_end = 0; JobID job_id; };
+
+struct Job {
+    JobID id;
+    SceneData scene_data;
+    JobConfiguration config;
+    std::vector<WorkUnit> work_units() const;  // job.rs:65-88 (via flux_work_units)
+};
+
+struct WorkUnitResult {
+    WorkUnit work_unit;
+    std::vector<std::vector<Color>> rows;
+};
+
+struct RenderEvent {  // manager.rs:16-22
+    enum Kind { RenderingStarted, ImageInfo, RowsReady, RenderingFinished } kind = RowsReady;
+    JobID job_id;
+    double time_s = 0;  // start_time / end_time (seconds on a steady clock)
+    std::string scene_name;
+    size_t width = 0, height = 0;
+    WorkUnitResult result;
+};
+
+struct WorkerInfo { size_t num_threads = 0; };  // manager.rs:221-230
+
+// unbounded MPMC channel with close(), enough of crossbeam::channel for the job loop
+template <typename T>
+class Channel {
+public:
+    void send(T v) {
+        { std::lock_guard<std::mutex> g(mu_); q_.push_back(std::move(v)); }
+        cv_.notify_one();
+    }
+    // returns nullopt once closed and drained (crossbeam: recv() -> Err)
+    std::optional<T> recv() {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return std::nullopt;
+        T v = std::move(q_.front());
+        q_.pop_front();
+        return v;
+    }
+    void close() {
+        { std::lock_guard<std::mutex> g(mu_); closed_ = true; }
+        cv_.notify_all();
+    }
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+    bool closed_ = false;
+};
+
+struct WaitGroup {  // crossbeam::sync::WaitGroup: done() once per clone, wait() for all
+    void add() { std::lock_guard<std::mutex> g(mu); n++; }
+    void done() { { std::lock_guard<std::mutex> g(mu); n--; } cv.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return n == 0; }); }
+    std::mutex mu; std::condition_variable cv; int n = 0;
+};
+
+// WorkerRequest = Option<(Box<Job>, Receiver<WorkUnit>, Sender<Option<RenderEvent>>, WaitGroup)> (manager.rs:36)
+struct WorkerRequest {
+    std::shared_ptr<Job> job;
+    std::shared_ptr<Channel<WorkUnit>> recv_unit;
+    std::shared_ptr<Channel<std::optional<RenderEvent>>> send_result;
+    std::shared_ptr<WaitGroup> wg;
+};
+
+class WorkerHandle {  // manager.rs:38-52
+public:
+    explicit WorkerHandle(std::shared_ptr<Channel<std::optional<WorkerRequest>>> s) : sender_(std::move(s)) {}
+    void send(std::shared_ptr<Job> j, std::shared_ptr<Channel<WorkUnit>> r,
+              std::shared_ptr<Channel<std::optional<RenderEvent>>> s, std::shared_ptr<WaitGroup> wg) const {
+        sender_->send(WorkerRequest{std::move(j), std::move(r), std::move(s), std::move(wg)});
+    }
+private:
+    std::shared_ptr<Channel<std::optional<WorkerRequest>>> sender_;
+};
+
+class Worker {  // trait Worker, manager.rs:232-236
+public:
+    virtual ~Worker() = default;
+    virtual WorkerHandle handle() const = 0;
+    virtual void stop() = 0;
+    virtual WorkerInfo info() const = 0;
+};
+
+// The GPU sibling of LocalWorker (workers.rs:26-103): one thread; per job it builds the context
+// (Scene::from_data + Camera::new) once, then renders the work units it pulls from the shared channel
+// and emits RenderEvent::RowsReady.
+class GpuWorker : public Worker {
+public:
+    GpuWorker(int device, uint64_t seed);
+    ~GpuWorker() override;
+    WorkerHandle handle() const override { return WorkerHandle(sender_); }
+    void stop() override;
+    WorkerInfo info() const override { return WorkerInfo{1}; }
+private:
+    void run();
+    int device_;
+    uint64_t seed_;
+    std::shared_ptr<Channel<std::optional<WorkerRequest>>> sender_;
+    std::thread thread_;
+    bool stopped_ = false;
+};
+
+// ImageBuilder (manager.rs:278-363): assembles RowsReady rows, prints the total time and writes
+// "<scene_name>.ppm" on RenderingFinished; rows never received are written as zeros (image.rs:55-59).
+class ImageBuilder {
+public:
+    ImageBuilder();
+    ~ImageBuilder();
+    std::shared_ptr<Channel<std::optional<RenderEvent>>> sender() const { return sender_; }
+    void stop();
+    std::string output_dir = ".";
+    double total_time_s = 0;
+    std::string written_path;
+private:
+    void run();
+    std::shared_ptr<Channel<std::optional<RenderEvent>>> sender_;
+    std::thread thread_;
+    bool stopped_ = false;
+};
+
+// The part of RenderManager the CLI needs (manager.rs:83-186): ImageInfo, RenderingStarted, feed the
+// work units of one job to every worker through one shared channel, wait, RenderingFinished.
+// Cancellation and the job queue thread are out of scope.
+void run_job(const Job &job, const std::vector<WorkerHandle> &workers,
+             const std::shared_ptr<Channel<std::optional<RenderEvent>>> &events);
+
+// SceneData -> flux_scene_desc (+ the shape storage it points to)
+struct AbiScene {
+    std::vector<flux_shape> shapes;
+    std::string name;
+    flux_scene_desc desc{};
+    explicit AbiScene(const SceneData &sd);
+};
+
+}  // namespace flux_host
