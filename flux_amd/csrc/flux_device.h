@@ -23,9 +23,9 @@ constexpr int kMatGlossy = 3;
 // fetched with scalar loads (s_load_dwordx8/x16) and live in SGPRs.
 struct DevShape {
     double px, py, pz;     // sphere centre | plane point
-    double radius;         // sphere radius
+    double rr;             // radius*radius (shapes.rs:179 recomputes it per ray); first 32 B = sphere quadratic
     double c0x, c0y, c0z;  // sphere AABB corner0 (Sphere::new, shapes.rs:154-169) | plane normal
-    double rr;             // radius*radius (shapes.rs:179 recomputes it per ray)
+    double radius;         // sphere radius
     double c1x, c1y, c1z;  // sphere AABB corner1
     double inv;            // invert_val: -1 if `invert` else +1 (shapes.rs:181)
     int32_t kind;

@@ -191,53 +191,61 @@ __device__ __forceinline__ int scene_hit(const RenderParams &P, const Ray &r, do
     const double a = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;  // shapes.rs:177
     const double denom = 2.0 * a;                               // shapes.rs:187
     int best = -1;
+    int bslot = -1;
     double tb = 0.0;
-    for (int s = 0; s < P.n_shapes; ++s) {
-        const DevShape &S = P.shapes[s];
-        double t = 0.0;
-        bool ok = false;
-        if (S.kind == kShapeSphere) {
-            // BoundingBox::hit: shapes.rs:98-133
-            double lox = (S.c0x - r.ox) * ax, hix = (S.c1x - r.ox) * ax;
-            double loy = (S.c0y - r.oy) * ay, hiy = (S.c1y - r.oy) * ay;
-            double loz = (S.c0z - r.oz) * az, hiz = (S.c1z - r.oz) * az;
-            double tx_min = ax >= 0.0 ? lox : hix, tx_max = ax >= 0.0 ? hix : lox;
-            double ty_min = ay >= 0.0 ? loy : hiy, ty_max = ay >= 0.0 ? hiy : loy;
-            double tz_min = az >= 0.0 ? loz : hiz, tz_max = az >= 0.0 ? hiz : loz;
-            double m0 = ty_min > tz_min ? ty_min : tz_min;  // max(a,b) = a > b ? a : b (shapes.rs:94-96)
-            double t0 = tx_min > m0 ? tx_min : m0;
-            double m1 = ty_max < tz_max ? ty_max : tz_max;  // min(a,b) = a < b ? a : b (shapes.rs:90-92)
-            double t1 = tx_max < m1 ? tx_max : m1;
-            if (t0 < t1 && t1 > kTMin) {
-                // Sphere::hit: shapes.rs:176-214
-                V3 temp = mk(r.ox - S.px, r.oy - S.py, r.oz - S.pz);
-                double b = 2.0 * (temp.x * r.dx + temp.y * r.dy + temp.z * r.dz);
-                double c = dot(temp, temp) - S.rr;
-                double disc = b * b - 4.0 * a * c;
-                if (!(disc < 0.0)) {
-                    double e = sqrt(disc);
-                    t = (-b - e) / denom;
-                    if (t > kTMin) {
-                        ok = true;
-                    } else {
-                        t = (-b + e) / denom;
-                        ok = t > kTMin;
-                    }
-                }
+    // The reference scans every shape and runs BoundingBox::hit before each sphere (shapes.rs:173).
+    // Same tests, regrouped for the machine: phase 1 walks the shapes with a wave-uniform index
+    // (operands in SGPRs, all lanes active) doing the plane test and only the box test of each sphere;
+    // phase 2 runs the sphere quadratic for each lane's OWN candidates, lowest index first, so the
+    // sqrt/divides execute with most lanes active instead of once per shape under a sparse mask.
+    // consider() applies min_by's rule order-independently (smaller t; equal t -> lower index).
+    for (int base = 0; base < P.n_shapes; base += 32) {
+        const int lim = (P.n_shapes - base) < 32 ? (P.n_shapes - base) : 32;
+        uint32_t cand = 0;
+        for (int k = 0; k < lim; ++k) {
+            const DevShape &S = P.shapes[base + k];
+            if (S.kind == kShapeSphere) {
+                // BoundingBox::hit: shapes.rs:98-133
+                double lox = (S.c0x - r.ox) * ax, hix = (S.c1x - r.ox) * ax;
+                double loy = (S.c0y - r.oy) * ay, hiy = (S.c1y - r.oy) * ay;
+                double loz = (S.c0z - r.oz) * az, hiz = (S.c1z - r.oz) * az;
+                double tx_min = ax >= 0.0 ? lox : hix, tx_max = ax >= 0.0 ? hix : lox;
+                double ty_min = ay >= 0.0 ? loy : hiy, ty_max = ay >= 0.0 ? hiy : loy;
+                double tz_min = az >= 0.0 ? loz : hiz, tz_max = az >= 0.0 ? hiz : loz;
+                double m0 = ty_min > tz_min ? ty_min : tz_min;  // max(a,b) = a > b ? a : b (shapes.rs:94-96)
+                double t0 = tx_min > m0 ? tx_min : m0;
+                double m1 = ty_max < tz_max ? ty_max : tz_max;  // min(a,b) = a < b ? a : b (shapes.rs:90-92)
+                double t1 = tx_max < m1 ? tx_max : m1;
+                if (t0 < t1 && t1 > kTMin) cand |= 1u << k;
+            } else {
+                // Plane::hit: shapes.rs:135-152 (normal stored in c0)
+                double num = (S.px - r.ox) * S.c0x + (S.py - r.oy) * S.c0y + (S.pz - r.oz) * S.c0z;
+                double den = r.dx * S.c0x + r.dy * S.c0y + r.dz * S.c0z;
+                double t = num / den;
+                if (t > kTMin) consider(t, base + k, -1, best, bslot, tb);
             }
-        } else {
-            // Plane::hit: shapes.rs:135-152 (normal stored in c0)
-            double num = (S.px - r.ox) * S.c0x + (S.py - r.oy) * S.c0y + (S.pz - r.oz) * S.c0z;
-            double den = r.dx * S.c0x + r.dy * S.c0y + r.dz * S.c0z;
-            t = num / den;
-            ok = t > kTMin;
         }
-        if (ok && (best < 0 || !(tb <= t))) {
-            best = s;
-            tb = t;
+        while (cand) {
+            const int k = __builtin_ctz(cand);
+            cand &= cand - 1;
+            const DevShape *S = P.shapes + (base + k);  // per-lane gather of 32 contiguous bytes
+            // Sphere::hit: shapes.rs:176-214
+            V3 temp = mk(r.ox - S->px, r.oy - S->py, r.oz - S->pz);
+            double b = 2.0 * (temp.x * r.dx + temp.y * r.dy + temp.z * r.dz);
+            double c = dot(temp, temp) - S->rr;
+            double disc = b * b - 4.0 * a * c;
+            if (!(disc < 0.0)) {
+                double e = sqrt(disc);
+                double t = (-b - e) / denom;
+                bool ok = t > kTMin;
+                if (!ok) {
+                    t = (-b + e) / denom;
+                    ok = t > kTMin;
+                }
+                if (ok) consider(t, base + k, -1, best, bslot, tb);
+            }
         }
     }
-    int bslot = -1;
     if (TRIS) {
         // triangles continue the scan with hit-order indices n_shapes + k
         if (P.bvh_stack > 0) {
