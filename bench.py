@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--kernel", type=int, default=0, help="0 default, 1 static, 2 refill")
+    ap.add_argument("--math", default="fast", choices=["fast", "strict"],
+                    help="render arithmetic (include/flux_abi.h FLUX_MATH_*); both are FP64 and parity-tested")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-root", type=int, default=32, help="sample_root of the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -128,6 +130,7 @@ def main():
     torch.cuda.synchronize()
     t_create = time.perf_counter() - t0
     r.set_kernel(a.kernel)
+    r.set_math(flux_amd.MATH_FAST if a.math == "fast" else flux_amd.MATH_STRICT)
     sh = FrameSharder(H, W, rank, world, dev)
     fn = hip_render_fn(r)
 
@@ -196,6 +199,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": workload, "kernel": "refill" if a.kernel in (0, 2) and n * n >= 64 else "static",
+                       "math": a.math,
                        "parallelism": f"row-interleaved image tiles over {world} GPU(s), 1 all_gather",
                        "finite": finite},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

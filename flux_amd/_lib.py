@@ -16,6 +16,7 @@ E_INVALID, E_DEVICE, E_NOMEM, E_IO = -1, -2, -3, -4
 SHAPE_SPHERE, SHAPE_PLANE = 0, 1
 MAT_MATTE, MAT_EMISSIVE, MAT_REFLECTIVE, MAT_GLOSSY = 0, 1, 2, 3
 KERNEL_DEFAULT, KERNEL_STATIC, KERNEL_REFILL = 0, 1, 2
+MATH_FAST, MATH_STRICT = 0, 1
 TABLE_PIXEL, TABLE_DISC, TABLE_HEMI = 0, 1, 2
 TRAVERSE_BVH, TRAVERSE_BRUTE = 0, 1
 NUM_STATS = 16
@@ -73,6 +74,9 @@ SYMBOLS = {
     "flux_render_rows_device": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P]),
     "flux_ctx_set_kernel": (C.c_int, [_P, C.c_int]),
     "flux_ctx_set_traversal": (C.c_int, [_P, C.c_int]),
+    "flux_ctx_set_math": (C.c_int, [_P, C.c_int]),
+    "flux_debug_fastmath": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), C.c_uint64]),
     "flux_ctx_bvh_info": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "flux_ctx_last_kernel_ms": (C.c_double, [_P]),
     "flux_ctx_enable_stats": (C.c_int, [_P, C.c_int]),

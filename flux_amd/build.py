@@ -11,7 +11,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "flux_amd", "csrc")
 HIP_SOURCES = ["abi.hip", "tables.hip", "render.hip", "bvh.cpp"]
-HIP_HEADERS = ["flux_device.h", "flux_rng.h", "flux_tables.h", "flux_bvh.h"]
+HIP_HEADERS = ["flux_device.h", "flux_rng.h", "flux_tables.h", "flux_bvh.h", "flux_math.h", "flux_math_coeffs.h",
+               "render_body.inc"]
 HIP_LIB = os.path.join(ROOT, "flux_amd", "libflux_hip.so")
 
 # -ffp-contract=off: the kernels keep the reference's operation order and never

@@ -73,6 +73,7 @@ struct flux_ctx {
     flux::BvhInfo bvh{};
     int traversal = FLUX_TRAVERSE_BVH;
     int variant = FLUX_KERNEL_DEFAULT;
+    int math = FLUX_MATH_FAST;
     // scratch framebuffer for the host-output path
     double *d_out = nullptr;
     size_t d_out_doubles = 0;
@@ -131,6 +132,10 @@ static void fill_material(flux::DevMaterial &dm, const flux_material &m) {
     dm.kind = m.kind;
     dm.exponent = m.exponent;
     dm.inv_e1 = 1.0 / (m.exponent + 1.0);
+    // powf(negative, e): +|x|^e for an even integral e, -|x|^e for an odd one, NaN otherwise
+    dm.exp_parity = 0;
+    if (std::isfinite(m.exponent) && std::floor(m.exponent) == m.exponent)
+        dm.exp_parity = (std::fabs(m.exponent) >= 9007199254740992.0 || std::fmod(m.exponent, 2.0) == 0.0) ? 1 : 2;
     double f[3];
     for (int ch = 0; ch < 3; ch++) {
         f[ch] = m.color[ch] * m.k;
@@ -221,6 +226,7 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
             d.radius = s.radius;
             d.rr = s.radius * s.radius;
             d.inv = s.invert ? -1.0 : 1.0;
+            d.inv_rad = d.inv / s.radius;
             // Sphere::new: shapes.rs:154-169
             d.c0x = s.p[0] - s.radius;
             d.c0y = s.p[1] - s.radius;
@@ -368,6 +374,37 @@ int flux_ctx_set_kernel(flux_ctx *ctx, int variant) {
     return FLUX_OK;
 }
 
+int flux_ctx_set_math(flux_ctx *ctx, int mode) {
+    if (!ctx) return fail(FLUX_E_INVALID, "null context");
+    if (mode != FLUX_MATH_FAST && mode != FLUX_MATH_STRICT) return fail(FLUX_E_INVALID, "unknown math mode %d", mode);
+    ctx->math = mode;
+    return FLUX_OK;
+}
+
+int flux_debug_fastmath(int device, int fn, const double *a, const double *b, double *out, uint64_t n) {
+    if (!a || !out) return fail(FLUX_E_INVALID, "null argument");
+    if (fn < 0 || fn > 9) return fail(FLUX_E_INVALID, "unknown function %d", fn);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+        return fail(FLUX_E_DEVICE, "no HIP device %d (this library has no CPU fallback)", device);
+    DeviceGuard guard(device);
+    if (n == 0) return FLUX_OK;
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    const size_t bytes = (size_t)n * sizeof(double);
+    hipError_t e = hipMalloc((void **)&da, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&dout, bytes);
+    if (e == hipSuccess && b) e = hipMalloc((void **)&db, bytes);
+    if (e == hipSuccess) e = hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && b) e = hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = flux::launch_fastmath_probe(fn, da, db, dout, (size_t)n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(da);
+    (void)hipFree(db);
+    (void)hipFree(dout);
+    if (e != hipSuccess) return fail(FLUX_E_DEVICE, "fastmath probe: %s", hipGetErrorString(e));
+    return FLUX_OK;
+}
+
 int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stride, uint64_t num_rows,
                             void *d_out_rgb, void *hip_stream) {
     if (!ctx) return fail(FLUX_E_INVALID, "null context");
@@ -389,7 +426,7 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
     p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
-    HIP_TRY(flux::launch_render(p, ctx->variant, stream));
+    HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
     HIP_TRY(hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
     return FLUX_OK;

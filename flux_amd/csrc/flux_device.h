@@ -30,7 +30,8 @@ struct DevShape {
     double inv;            // invert_val: -1 if `invert` else +1 (shapes.rs:181)
     int32_t kind;
     int32_t pad0;
-    double pad1[3];
+    double inv_rad;        // inv / radius (FAST path: the sphere normal's scale in one rounding)
+    double pad1[2];
 };
 static_assert(sizeof(DevShape) == 128, "DevShape layout");
 
@@ -44,7 +45,7 @@ struct DevMaterial {
     double exponent;  // Glossy reflect_exponent
     double inv_e1;    // 1/(exponent+1) (samplers/src/lib.rs:136)
     int32_t kind;
-    int32_t pad0;
+    int32_t exp_parity;  // Glossy exponent: 1 even integer, 2 odd integer, 0 not integral (powf of a negative base)
     double pad1[2];
 };
 static_assert(sizeof(DevMaterial) == 64, "DevMaterial layout");

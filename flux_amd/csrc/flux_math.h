@@ -1,0 +1,115 @@
+// flux_math.h -- FP64 elementary functions for the FAST render path on gfx950.
+//
+// The render loop is FP64-VALU bound (DESIGN.md "Kernels"), and most of its instructions sit in
+// IEEE division (v_div_scale/v_rcp/6 fma/v_div_fmas/v_div_fixup), sqrt, and OCML's correctly-rounded-ish
+// pow (~220 VALU) / sincos (~150).  These replacements keep full double precision (<= ~2 ulp, measured
+// on the device by tests/test_gpu_fastmath.py through flux_debug_fastmath) but drop the scaling /
+// special-case scaffolding the render loop's operand ranges never need:
+//   frsqrt   v_rsq_f64 seed + one cubic (Halley) step                      6 VALU  (sqrt+3 div ~ 50)
+//   fsqrt    v_rsq_f64 seed + Goldschmidt step + residual correction       9 VALU  (OCML 22)
+//   fdiv     v_rcp_f64 seed + cubic step + residual correction             8 VALU  (IEEE 11)
+//   flog2    frexp + s=(m-1)/(m+1) + degree-7 polynomial in s^2           ~28 VALU  (OCML 89)
+//   fexp2    rndne + degree-11 polynomial + ldexp                         ~16 VALU  (OCML 42)
+//   fpow     fexp2(y*flog2(x)), x >= 0                                    ~48 VALU  (OCML 224)
+//   fsincos2pi  exact quarter-turn reduction of 2*pi*x + degree-6/7 polynomials  ~32 VALU (OCML 154)
+// Polynomial coefficients: flux_math_coeffs.h (generated, scripts/fit_fast_math.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "flux_math_coeffs.h"
+
+namespace flux {
+namespace fastmath {
+
+__device__ __forceinline__ double ffma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// 1/sqrt(x), x > 0 finite normal
+__device__ __forceinline__ double frsqrt(double x) {
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double t = x * y0;
+    const double e = ffma(-t, y0, 1.0);              // 1 - x*y0^2
+    const double a = ffma(0.375, e, 0.5);            // y0*(1 + e/2 + 3e^2/8): error O(e^3)
+    return ffma(y0 * e, a, y0);
+}
+
+// sqrt(x), x >= 0 (x below 1e-300, including 0 and tiny negatives from rounding, gives ~0)
+__device__ __forceinline__ double fsqrt(double x) {
+    const double xs = __builtin_fmax(x, 1e-300);
+    const double y0 = __builtin_amdgcn_rsq(xs);
+    double g = x * y0;
+    double h = 0.5 * y0;
+    const double r = ffma(-h, g, 0.5);
+    g = ffma(g, r, g);
+    h = ffma(h, r, h);
+    const double d = ffma(-g, g, x);
+    return ffma(d, h, g);
+}
+
+// a/b for finite normal b (no scaling: |b| well inside the exponent range)
+__device__ __forceinline__ double fdiv(double a, double b) {
+    const double r0 = __builtin_amdgcn_rcp(b);
+    const double e = ffma(-b, r0, 1.0);
+    const double c = r0 * e;
+    const double r = r0 + ffma(c, e, c);             // r0*(1 + e + e^2)
+    const double q = a * r;
+    const double rem = ffma(-q, b, a);
+    return ffma(rem, r, q);
+}
+
+template <int N>
+__device__ __forceinline__ double horner(const double (&c)[N], double x) {
+    double r = c[N - 1];
+#pragma unroll
+    for (int k = N - 2; k >= 0; --k) r = ffma(r, x, c[k]);
+    return r;
+}
+
+// log2(x), x > 0 finite normal.  (x == 0 returns a large negative finite number, see fpow.)
+__device__ __forceinline__ double flog2(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);        // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;                                // [sqrt(.5), sqrt(2))
+    k = lo ? k - 1 : k;
+    const double s = fdiv(m - 1.0, m + 1.0);
+    const double w = s * s;
+    const double p = horner(kLog2Poly, w);
+    return ffma(s, p, (double)k);
+}
+
+// 2^t for t <= ~1000 (clamped below at -1100 -> 0)
+__device__ __forceinline__ double fexp2(double t) {
+    t = __builtin_fmax(t, -1100.0);
+    const double n = __builtin_rint(t);
+    const double f = t - n;
+    const double p = horner(kExp2Poly, f);
+    return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
+// pow(x, y) for x >= 0, y > 0 finite (the render loop's domain: x = 1 - sample.y or a cosine).
+__device__ __forceinline__ double fpow_pos(double x, double y) {
+    const double r = fexp2(y * flog2(x));
+    return x > 0.0 ? r : 0.0;
+}
+
+// (sin, cos) of 2*pi*x, x in [0, 1]: quarter-turn reduction is exact in f64
+__device__ __forceinline__ void fsincos2pi(double x, double &s, double &c) {
+    const double n = __builtin_rint(4.0 * x);
+    const double f = ffma(4.0, x, -n);               // exact, |f| <= 1/2
+    const double w = f * f;
+    const double s0 = f * horner(kSinQPoly, w);
+    const double c0 = horner(kCosQPoly, w);
+    const int q = (int)n;
+    const bool swap = (q & 1) != 0;
+    double ss = swap ? c0 : s0;
+    double cc = swap ? s0 : c0;
+    // quadrant signs: sin negative for q = 2,3; cos negative for q = 1,2
+    ss = (q & 2) ? -ss : ss;
+    cc = ((q + 1) & 2) ? -cc : cc;
+    s = ss;
+    c = cc;
+}
+
+}  // namespace fastmath
+}  // namespace flux

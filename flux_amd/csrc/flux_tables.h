@@ -13,7 +13,12 @@ hipError_t generate_tables(uint64_t seed, uint32_t S, uint32_t D, uint32_t n, ui
                            hipStream_t stream);
 hipError_t hemi_to_aos(size_t SD, size_t N, const double *in, double *out, hipStream_t stream);
 
-// Camera::render (trace.rs:53-97).  variant: FLUX_KERNEL_STATIC / FLUX_KERNEL_REFILL.
-hipError_t launch_render(const RenderParams &p, int variant, hipStream_t stream);
+// Camera::render (trace.rs:53-97).  variant: FLUX_KERNEL_STATIC / FLUX_KERNEL_REFILL;
+// math: FLUX_MATH_FAST / FLUX_MATH_STRICT (render_body.inc).
+hipError_t launch_render(const RenderParams &p, int variant, int math, hipStream_t stream);
+
+// flux_math.h under test: out[i] = fn(a[i], b[i]) on the device (b may be null).
+hipError_t launch_fastmath_probe(int fn, const double *a, const double *b, double *out, size_t n,
+                                 hipStream_t stream);
 
 }  // namespace flux

@@ -82,6 +82,10 @@ class Renderer:
     def set_kernel(self, variant: int):
         _lib.check(_lib.lib.flux_ctx_set_kernel(self._handle(), variant))
 
+    def set_math(self, mode: int):
+        """MATH_FAST (default) or MATH_STRICT (reference operation order); include/flux_abi.h."""
+        _lib.check(_lib.lib.flux_ctx_set_math(self._handle(), mode))
+
     def last_kernel_ms(self) -> float:
         return float(_lib.lib.flux_ctx_last_kernel_ms(self._handle()))
 
@@ -148,3 +152,17 @@ def write_ppm(path: str, rgb: np.ndarray, rows_present=None):
         assert rp_arr.shape == (h,)
         rp = rp_arr.ctypes.data_as(C.POINTER(C.c_uint8))
     _lib.check(_lib.lib.flux_write_ppm(path.encode(), rgb.ctypes.data_as(C.POINTER(C.c_double)), w, h, rp))
+
+
+def debug_fastmath(fn: int, a, b=None, device: int = 0) -> np.ndarray:
+    """out[i] = fn(a[i], b[i]) evaluated on the device by csrc/flux_math.h (test hook)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.empty_like(a)
+    pa = a.ctypes.data_as(C.POINTER(C.c_double))
+    pb = None
+    if b is not None:
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        assert b.shape == a.shape
+        pb = b.ctypes.data_as(C.POINTER(C.c_double))
+    _lib.check(_lib.lib.flux_debug_fastmath(device, fn, pa, pb, out.ctypes.data_as(C.POINTER(C.c_double)), a.size))
+    return out

@@ -171,6 +171,17 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
 #define FLUX_KERNEL_REFILL 2
 int flux_ctx_set_kernel(flux_ctx *ctx, int variant);
 
+/* Arithmetic of the render kernels -- both FP64 end to end, both checked against the oracle at the
+ * north-star tolerance (1e-4 per channel):
+ *   FLUX_MATH_FAST (default): the reference's estimator evaluated for the machine -- FMA contraction,
+ *       division/sqrt/pow/sincos from flux_math.h (<= ~2 ulp), no BoundingBox::hit pre-test (implied by
+ *       the sphere quadratic), path throughput multiplied front to back;
+ *   FLUX_MATH_STRICT: the reference's operation order, no contraction, IEEE division/sqrt, OCML
+ *       pow/sincos, BoundingBox::hit before every sphere, (f,s) stack folded deepest bounce first. */
+#define FLUX_MATH_FAST 0
+#define FLUX_MATH_STRICT 1
+int flux_ctx_set_math(flux_ctx *ctx, int mode);
+
 /* Triangle traversal (extension): 0 = BVH with a per-lane LDS stack (default), 1 = brute force over
  * all triangles in index order (the definition the BVH must reproduce exactly; parity tests). */
 #define FLUX_TRAVERSE_BVH 0
@@ -206,6 +217,11 @@ int flux_ctx_copy_row_perm(flux_ctx *ctx, uint64_t row, int32_t *out, uint64_t o
 int flux_ctx_camera_basis(flux_ctx *ctx, double uvw[9]); /* CameraBasis::new scene.rs:28-35 */
 /* bytes of HBM held by the context's tables + scene */
 uint64_t flux_ctx_device_bytes(flux_ctx *ctx);
+
+/* Test hook for csrc/flux_math.h: out[i] = fn(a[i], b[i]) evaluated ON THE DEVICE (host pointers in,
+ * host pointer out; b may be NULL for unary functions).  fn: 0 frsqrt, 1 fsqrt, 2 fdiv, 3 flog2,
+ * 4 fexp2, 5 fpow_pos, 6 sin(2 pi a), 7 cos(2 pi a), 8 raw v_rsq_f64, 9 raw v_rcp_f64. */
+int flux_debug_fastmath(int device, int fn, const double *a, const double *b, double *out, uint64_t n);
 
 /* Job::work_units (job.rs:65-88), including its `i < H-1` loop guard.  Writes
  * at most `cap` units and returns the number the reference would issue, or a
