@@ -18,7 +18,10 @@ HIP_LIB = os.path.join(ROOT, "flux_amd", "libflux_hip.so")
 # -ffp-contract=off: the kernels keep the reference's operation order and never
 # fuse a*b+c (rustc does not contract); see DESIGN.md "Numerics".
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-             "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+             "-fno-fast-math", "-Wall", "-Wno-unused-function",
+             # machine LICM hoists the ~35 f64 polynomial coefficients of flux_math.h into VGPRs for the
+             # whole render loop (+60 VGPRs, one wave/SIMD less); rematerialising them at the use is free
+             "-mllvm", "-disable-machine-licm"]
 
 
 def _newer(target, deps):

@@ -62,6 +62,7 @@ struct flux_ctx {
     uint32_t n = 0, N = 0, D = 0, S = 0, W = 0, H = 0;
     flux::DevShape *d_shapes = nullptr;
     flux::DevMaterial *d_mats = nullptr;
+    unsigned char *d_fscene = nullptr;  // FAST path: scan spheres | scan planes | hit records
     double2 *d_pix = nullptr, *d_disc = nullptr;
     double *d_hemi = nullptr;
     int32_t *d_rowperm = nullptr;
@@ -102,6 +103,7 @@ static void free_ctx(flux_ctx *c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     (void)hipFree(c->d_shapes);
     (void)hipFree(c->d_mats);
+    (void)hipFree(c->d_fscene);
     (void)hipFree(c->d_pix);
     (void)hipFree(c->d_disc);
     (void)hipFree(c->d_hemi);
@@ -241,6 +243,42 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
         }
         fill_material(mats[i], s.material);
     }
+    // FAST path layout of the same shapes: scan records (spheres, planes) + hit records in scan order
+    std::vector<flux::DevScanSphere> fsph;
+    std::vector<flux::DevScanPlane> fpln;
+    std::vector<flux::DevHitRec> frec_s, frec_p;
+    for (size_t i = 0; i < ns; i++) {
+        const flux::DevShape &d = shapes[i];
+        const flux::DevMaterial &m = mats[i];
+        flux::DevHitRec r;
+        std::memset(&r, 0, sizeof(r));
+        r.fr = m.fr; r.fg = m.fg; r.fb = m.fb;
+        r.exponent = m.exponent; r.inv_e1 = m.inv_e1;
+        r.shape_kind = d.kind; r.mat_kind = m.kind; r.exp_parity = m.exp_parity; r.orig_id = (int32_t)i;
+        if (d.kind == flux::kShapeSphere) {
+            r.cx = d.px; r.cy = d.py; r.cz = d.pz; r.inv_rad = d.inv_rad;
+            fsph.push_back(flux::DevScanSphere{d.px, d.py, d.pz, d.rr});
+            frec_s.push_back(r);
+        } else {
+            r.cx = d.c0x; r.cy = d.c0y; r.cz = d.c0z;
+            flux::DevScanPlane pl;
+            std::memset(&pl, 0, sizeof(pl));
+            pl.px = d.px; pl.py = d.py; pl.pz = d.pz; pl.nx = d.c0x; pl.ny = d.c0y; pl.nz = d.c0z; pl.id = (int32_t)i;
+            fpln.push_back(pl);
+            frec_p.push_back(r);
+        }
+    }
+    const size_t fs_sph_bytes = (fsph.size() + 1) * sizeof(flux::DevScanSphere);  // +1: the scan reads one record ahead
+    const size_t fs_pln_bytes = (fpln.size() + 1) * sizeof(flux::DevScanPlane);
+    const size_t fs_rec_bytes = (ns + 1) * sizeof(flux::DevHitRec);
+    std::vector<unsigned char> fscene(fs_sph_bytes + fs_pln_bytes + fs_rec_bytes, 0);
+    if (!fsph.empty()) std::memcpy(fscene.data(), fsph.data(), fsph.size() * sizeof(flux::DevScanSphere));
+    if (!fpln.empty()) std::memcpy(fscene.data() + fs_sph_bytes, fpln.data(), fpln.size() * sizeof(flux::DevScanPlane));
+    if (!frec_s.empty()) std::memcpy(fscene.data() + fs_sph_bytes + fs_pln_bytes, frec_s.data(), frec_s.size() * sizeof(flux::DevHitRec));
+    if (!frec_p.empty())
+        std::memcpy(fscene.data() + fs_sph_bytes + fs_pln_bytes + frec_s.size() * sizeof(flux::DevHitRec), frec_p.data(),
+                    frec_p.size() * sizeof(flux::DevHitRec));
+
     // extension: meshes -> triangle records (hit order: after all shapes) + BVH
     std::vector<flux::DevTri> tris;
     std::vector<flux::DevNode> nodes;
@@ -326,6 +364,7 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     };
     alloc((void **)&c->d_shapes, shapes.size() * sizeof(flux::DevShape));
     alloc((void **)&c->d_mats, mats.size() * sizeof(flux::DevMaterial));
+    alloc((void **)&c->d_fscene, fscene.size());
     alloc((void **)&c->d_pix, pix_bytes);
     alloc((void **)&c->d_disc, pix_bytes);
     alloc((void **)&c->d_hemi, hemi_bytes);
@@ -339,6 +378,7 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     }
     if (e == hipSuccess) e = hipMemcpy(c->d_shapes, shapes.data(), shapes.size() * sizeof(flux::DevShape), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_mats, mats.data(), mats.size() * sizeof(flux::DevMaterial), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_fscene, fscene.data(), fscene.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(c->d_stats, 0, FLUX_NUM_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -362,6 +402,11 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     rp.nodes = c->d_nodes;
     rp.n_tris = (int32_t)tris.size();
     rp.bvh_stack = (int32_t)c->bvh.max_depth;
+    rp.fsph = reinterpret_cast<const flux::DevScanSphere *>(c->d_fscene);
+    rp.fpln = reinterpret_cast<const flux::DevScanPlane *>(c->d_fscene + fs_sph_bytes);
+    rp.frec = reinterpret_cast<const flux::DevHitRec *>(c->d_fscene + fs_sph_bytes + fs_pln_bytes);
+    rp.n_sph = (int32_t)fsph.size();
+    rp.n_pln = (int32_t)fpln.size();
     *out = c;
     return FLUX_OK;
 }

@@ -50,6 +50,34 @@ struct DevMaterial {
 };
 static_assert(sizeof(DevMaterial) == 64, "DevMaterial layout");
 
+// ---- FAST path scene: the same shapes, laid out for the scan / for the shade gather -------------
+// Scan records are walked with a wave-uniform index (scalar loads, software-pipelined one record
+// ahead); spheres and planes are separated so the sphere loop has no branch on the shape kind.
+struct DevScanSphere {  // 32 B: one s_load_dwordx8
+    double px, py, pz, rr;
+};
+static_assert(sizeof(DevScanSphere) == 32, "DevScanSphere layout");
+struct DevScanPlane {   // 64 B
+    double px, py, pz;  // point
+    double nx, ny, nz;  // normal as stored (never flipped / normalised, shapes.rs:135-152)
+    int32_t id;         // index in YAML order (tie-break, scene.rs:156-160)
+    int32_t pad0;
+    double pad1;
+};
+static_assert(sizeof(DevScanPlane) == 64, "DevScanPlane layout");
+// Everything Scene::shade needs about the winning shape, fetched in ONE per-lane batch (6 x 16 B) after
+// the scan instead of a chain of dependent loads.  Indexed in scan order: spheres, then planes.
+struct DevHitRec {      // 96 B
+    double cx, cy, cz;  // sphere centre | plane normal
+    double inv_rad;     // sphere: invert_val / radius
+    double fr, fg, fb;  // material constants as in DevMaterial
+    double exponent, inv_e1;
+    int32_t shape_kind, mat_kind;
+    int32_t exp_parity, orig_id;
+    double pad;
+};
+static_assert(sizeof(DevHitRec) == 96, "DevHitRec layout");
+
 // Kernel argument block (by value -> kernarg segment -> scalar loads).
 struct RenderParams {
     // camera (trace.rs:44-60, scene.rs:28-35)
@@ -82,6 +110,11 @@ struct RenderParams {
     const DevNode *nodes;  // node 0 = root
     int32_t n_tris;
     int32_t bvh_stack;     // per-lane traversal stack entries (= BVH max depth); 0 = brute force
+    // FAST path scene (same shapes as `shapes`/`mats`)
+    const DevScanSphere *fsph;
+    const DevScanPlane *fpln;
+    const DevHitRec *frec;  // [n_sph + n_pln]
+    int32_t n_sph, n_pln;
 };
 
 }  // namespace flux

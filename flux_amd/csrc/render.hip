@@ -43,11 +43,15 @@
 #ifndef FLUX_WAVES_PER_EU
 #define FLUX_WAVES_PER_EU 3
 #endif
+#ifndef FLUX_WAVES_PER_EU_FAST
+#define FLUX_WAVES_PER_EU_FAST 4
+#endif
 
 
 // The loop itself lives in render_body.inc and is compiled twice (see its header): the STRICT
 // arithmetic (reference operation order, no contraction) and the FAST arithmetic (FMA + flux_math.h).
 #define FLUX_FAST 0
+#define FLUX_WPE FLUX_WAVES_PER_EU
 #pragma clang fp contract(off)
 namespace flux {
 namespace strict {
@@ -55,8 +59,10 @@ namespace strict {
 }  // namespace strict
 }  // namespace flux
 #undef FLUX_FAST
+#undef FLUX_WPE
 
 #define FLUX_FAST 1
+#define FLUX_WPE FLUX_WAVES_PER_EU_FAST
 #pragma clang fp contract(fast)
 namespace flux {
 namespace fast {
@@ -64,6 +70,7 @@ namespace fast {
 }  // namespace fast
 }  // namespace flux
 #undef FLUX_FAST
+#undef FLUX_WPE
 #pragma clang fp contract(off)
 
 namespace flux {

@@ -6,14 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VAR_DIR = os.path.join(ROOT, "flux_amd", "variants")
 VARIANTS = {
-    "base": [],
-    "fma": ["-ffp-contract=fast"],
-    "w3": ["-DFLUX_WAVES_PER_EU=3"],
-    "w4": ["-DFLUX_WAVES_PER_EU=4"],
-    "b64": ["-DFLUX_BLOCK_THREADS=64"],
-    "b64w3": ["-DFLUX_BLOCK_THREADS=64", "-DFLUX_WAVES_PER_EU=3"],
-    "fma_w3": ["-ffp-contract=fast", "-DFLUX_WAVES_PER_EU=3"],
-    "fma_w4": ["-ffp-contract=fast", "-DFLUX_WAVES_PER_EU=4"],
+    "f4": ["-DFLUX_WAVES_PER_EU_FAST=4"],
+    "f5": ["-DFLUX_WAVES_PER_EU_FAST=5"],
+    "f6": ["-DFLUX_WAVES_PER_EU_FAST=6"],
 }
 if "--run" not in sys.argv:
     from flux_amd import build
@@ -42,7 +37,7 @@ for v in (1, 2):
     err = float(np.abs(img - np.load(ref_path)).max())
     print("  variant %%d: %%8.2f ms  %%8.1f Msamples/s  max|d| vs first = %%.3e" %% (v, best, 800*600*n*n/best/1e3, err), flush=True)
 ''' % (ROOT, ROOT)
-    for lib in sorted(glob.glob(os.path.join(VAR_DIR, "*.so")), key=lambda p: (not p.endswith("_base.so"), p)):
+    for lib in sorted(glob.glob(os.path.join(VAR_DIR, "*.so")), key=lambda p: (not p.endswith("_f4.so"), p)):
         print(os.path.basename(lib), flush=True)
         env = dict(os.environ, FLUX_HIP_LIB=lib)
         subprocess.run([sys.executable, "-c", code], env=env, check=False)
