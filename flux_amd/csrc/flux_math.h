@@ -74,7 +74,7 @@ __device__ __forceinline__ double flog2(double x) {
     k = lo ? k - 1 : k;
     const double s = fdiv(m - 1.0, m + 1.0);
     const double w = s * s;
-    const double p = horner(kLog2Poly, w);
+    const double p = poly_log2(w);
     return ffma(s, p, (double)k);
 }
 
@@ -83,7 +83,7 @@ __device__ __forceinline__ double fexp2(double t) {
     t = __builtin_fmax(t, -1100.0);
     const double n = __builtin_rint(t);
     const double f = t - n;
-    const double p = horner(kExp2Poly, f);
+    const double p = poly_exp2(f);
     return __builtin_amdgcn_ldexp(p, (int)n);
 }
 
@@ -98,8 +98,8 @@ __device__ __forceinline__ void fsincos2pi(double x, double &s, double &c) {
     const double n = __builtin_rint(4.0 * x);
     const double f = ffma(4.0, x, -n);               // exact, |f| <= 1/2
     const double w = f * f;
-    const double s0 = f * horner(kSinQPoly, w);
-    const double c0 = horner(kCosQPoly, w);
+    const double s0 = f * poly_sinq(w);
+    const double c0 = poly_cosq(w);
     const int q = (int)n;
     const bool swap = (q & 1) != 0;
     double ss = swap ? c0 : s0;
