@@ -34,6 +34,13 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             for k in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Workgroup_Size", "Grid_Size"):
                 meta[name][k] = float(row[k])
 
+# FETCH_SIZE calibration kernels (scripts/calib_fetch.hip): known 1 GiB per launch
+calib = collections.defaultdict(list)
+for f in glob.glob(os.path.join(src, "pmc_calib", "*", "*counter_collection.csv")):
+    for row in csv.DictReader(open(f)):
+        if row["Counter_Name"] == "FETCH_SIZE" and row["Kernel_Name"].startswith("read"):
+            calib[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]) * 1024.0)
+
 bench = {}
 for f in glob.glob(os.path.join(src, "bench_*.json")):
     try:
@@ -42,6 +49,10 @@ for f in glob.glob(os.path.join(src, "bench_*.json")):
         pass
 
 out = {"tag": tag, "kernels": {}, "bench_lines": bench}
+if calib:
+    out["fetch_calibration"] = {k: {"fetch_size_bytes": v, "true_bytes": float(1 << 30),
+                                    "true_over_reported": [float(1 << 30) / x if x else None for x in v]}
+                                for k, v in calib.items()}
 workload = None
 for b in bench.values():
     workload = b.get("config", {}).get("workload", workload)
@@ -56,7 +67,12 @@ for name, cs in counters.items():
 if main and "FETCH_SIZE" in main and "WRITE_SIZE" in main:
     # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in units of 1024 B
     out["hbm_bytes_per_launch_raw"] = (main["FETCH_SIZE"] + main["WRITE_SIZE"]) * 1024.0
+    # correction factor for FETCH_SIZE: measured by the calibration kernels of this very run when present
+    # (both of this kernel's access widths, 16 B and 8 B per lane, read exactly 1/2 on gfx950), else argv/1.0
     scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+    if calib and len(sys.argv) <= 2:
+        ratios = [float(1 << 30) / x for v in calib.values() for x in v if x]
+        scale = sum(ratios) / len(ratios)
     out["fetch_scale"] = scale
     out["hbm_bytes_per_launch"] = (main["FETCH_SIZE"] * scale + main["WRITE_SIZE"]) * 1024.0
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
