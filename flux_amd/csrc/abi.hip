@@ -190,7 +190,7 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
                             (unsigned long long)m, me.indices[k], (unsigned long long)me.num_vertices);
         total_tris += me.num_triangles;
     }
-    if (total_tris > (1ull << 30))
+    if (total_tris >= (1ull << 27))  // leaf references pack (first << 3 | count) into 31 bits
         return fail(FLUX_E_INVALID, "too many triangles: %llu", (unsigned long long)total_tris);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -405,6 +405,7 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     rp.fsph = reinterpret_cast<const flux::DevScanSphere *>(c->d_fscene);
     rp.fpln = reinterpret_cast<const flux::DevScanPlane *>(c->d_fscene + fs_sph_bytes);
     rp.frec = reinterpret_cast<const flux::DevHitRec *>(c->d_fscene + fs_sph_bytes + fs_pln_bytes);
+    rp.bvh_mag = c->bvh.mag;
     rp.n_sph = (int32_t)fsph.size();
     rp.n_pln = (int32_t)fpln.size();
     *out = c;

@@ -177,7 +177,7 @@ struct Builder {
             const Box bx = range_box(rb[side], re[side]);
             int32_t link, count = 0;
             if (cnt <= (uint32_t)kBvhLeafSize) {
-                link = ~(int32_t)rb[side];
+                link = ~(int32_t)((rb[side] << 3) | cnt);  // leaf reference: ~((first << 3) | count)
                 count = (int32_t)cnt;
                 info.max_leaf = std::max<uint64_t>(info.max_leaf, cnt);
             } else {
@@ -236,10 +236,10 @@ void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &
         nodes.emplace_back();
         DevNode &N = nodes[0];
         B.store_box(N.lo0, N.hi0, all);
-        N.child0 = ~0;
+        N.child0 = ~(int32_t)((0u << 3) | (uint32_t)tris.size());
         N.count0 = (int32_t)tris.size();
         Builder::empty_box(N.lo1, N.hi1);
-        N.child1 = ~0;
+        N.child1 = ~0;  // empty leaf: never visited (inverted box), count 0
         N.count1 = 0;
         info.max_depth = 1;
         info.max_leaf = tris.size();
@@ -250,6 +250,7 @@ void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &
     for (size_t k = 0; k < tris.size(); k++) sorted[k] = tris[B.order[k]];
     tris.swap(sorted);
     info.nodes = nodes.size();
+    info.mag = mag;
     info.build_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
                         std::chrono::steady_clock::now() - t0).count();
 }

@@ -21,7 +21,8 @@ static_assert(sizeof(DevTri) == 128, "DevTri layout");
 
 // Binary BVH node, 64 B: the bounds of BOTH children (f32, rounded outward and padded, so the
 // slab test is conservative w.r.t. the f64 triangle test) and their links.
-// child >= 0: inner node index; child < 0: leaf holding triangles [~child, ~child + count).
+// child >= 0: inner node index; child < 0: leaf reference ~((first << 3) | count) holding triangles
+// [first, first + count), count <= 7, first < 2^27.
 struct DevNode {
     float lo0[3], hi0[3];
     float lo1[3], hi1[3];
@@ -36,6 +37,7 @@ constexpr int kBvhLeafSize = 4;
 
 struct BvhInfo {
     uint64_t nodes = 0, tris = 0, max_depth = 0, max_leaf = 0, build_us = 0;
+    double mag = 0.0;  // largest |coordinate| of any vertex (scale of the f32 slab test's padding)
 };
 
 // Binned-SAH top-down build.  `tris` is reordered into leaf order (ids keep the original order).

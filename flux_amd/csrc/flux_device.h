@@ -115,6 +115,7 @@ struct RenderParams {
     const DevScanPlane *fpln;
     const DevHitRec *frec;  // [n_sph + n_pln]
     int32_t n_sph, n_pln;
+    double bvh_mag;  // largest |coordinate| of any mesh vertex (padding scale of the f32 slab test)
 };
 
 }  // namespace flux

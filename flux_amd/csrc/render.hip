@@ -43,6 +43,12 @@
 #ifndef FLUX_WAVES_PER_EU
 #define FLUX_WAVES_PER_EU 3
 #endif
+#ifndef FLUX_WPE_BVH
+#define FLUX_WPE_BVH 4            // waves/SIMD of the BVH traversal kernel
+#endif
+#ifndef FLUX_BVH_REFILL_AT
+#define FLUX_BVH_REFILL_AT 16     // lanes that must be waiting for shading before the wave leaves traversal
+#endif
 #ifndef FLUX_WAVES_PER_EU_FAST
 #define FLUX_WAVES_PER_EU_FAST 4
 #endif

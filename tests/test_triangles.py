@@ -101,10 +101,30 @@ def test_bvh_equals_bruteforce_equals_oracle(flux, oracle_mod, demo2, nx, nz, va
         r.set_kernel(variant)
         info = r.bvh_info()
         assert info["triangles"] == 2 * nx * nz and info["max_leaf"] <= 4 and info["max_depth"] <= 64
+        r.enable_stats(True)
+        r.stats(reset=True)
         bvh = r.render_frame()
+        st_bvh = r.stats(reset=True)
         r.set_traversal(flux._lib.TRAVERSE_BRUTE)
         brute = r.render_frame()
-        assert np.array_equal(bvh, brute)          # the BVH returns exactly the brute-force hits
+        st_brute = r.stats(reset=True)
+        # the BVH returns exactly the brute-force hits: every path takes the same decisions ...
+        for k in ("samples", "segments", "matte_bounces", "glossy_bounces", "specular_bounces", "emissive_hits",
+                  "misses", "depth_exhausted"):
+            assert st_bvh[k] == st_brute[k], k
+        # ... and the same per-sample values; the refill variant's BVH kernel (a traversal state machine,
+        # render_body.inc) hands a pixel's samples to lanes in a different order, so its per-pixel SUM may
+        # differ in the last bits; the static variant uses one code path for both and is bit-equal
+        if variant == 1:
+            assert np.array_equal(bvh, brute)
+        else:
+            assert max_abs_diff(bvh, brute) < 1e-13
+        r.set_math(flux.MATH_STRICT)               # reference operation order: one kernel for both, bit-equal
+        r.enable_stats(False)
+        brute_s = r.render_frame()
+        r.set_traversal(flux._lib.TRAVERSE_BVH)
+        assert np.array_equal(r.render_frame(), brute_s)
+        assert max_abs_diff(brute_s, brute) < 1e-9
     if nx * nz <= 24 * 16:
         want = oracle_mod.Oracle(sd, cfg, seed=3).render_frame(threads=8)
         assert max_abs_diff(bvh, want) < 1e-4
@@ -128,7 +148,7 @@ def test_bvh_stats_and_degenerate_meshes(flux, oracle_mod, demo2):
         assert st2["tris_tested"] == st2["segments"] * 2400 and st2["bvh_nodes"] == 0
         for k in ("samples", "segments", "matte_bounces", "glossy_bounces", "emissive_hits"):
             assert st[k] == st2[k]
-        assert np.array_equal(a, b)
+        assert max_abs_diff(a, b) < 1e-13  # same hits; the BVH kernel sums a pixel's samples in another order
     # many coincident + zero-area triangles: ties resolve to the lowest index, degenerate ones never hit
     v = np.array([[0, 0.5, 0], [2, 0.5, 0], [0, 0.5, 2], [1, 0.5, 1]], dtype=np.float64)
     t = np.array([[0, 1, 2]] * 40 + [[0, 3, 3]] * 10 + [[0, 2, 1]] * 7, dtype=np.uint32)
@@ -136,7 +156,13 @@ def test_bvh_stats_and_degenerate_meshes(flux, oracle_mod, demo2):
     sd2.shapes = list(sd2.shapes) + [MeshData(v, t, flux.EmissiveData((0.2, 1.0, 0.1), 3.0))]
     cfg = flux.JobConfiguration(4, 5, 50)
     with flux.Renderer(sd2, cfg, seed=1) as r:
-        a = r.render_frame()
+        a = r.render_frame()  # 16 spp: static kernel, one code path for both traversals
         r.set_traversal(flux._lib.TRAVERSE_BRUTE)
         assert np.array_equal(a, r.render_frame())
     assert max_abs_diff(a, oracle_mod.Oracle(sd2, cfg, seed=1).render_frame(threads=4)) < 1e-4
+    cfg8 = flux.JobConfiguration(8, 5, 50)  # 64 spp: the BVH state-machine kernel on the same degenerate mesh
+    with flux.Renderer(sd2, cfg8, seed=1) as r:
+        a8 = r.render_frame()
+        r.set_traversal(flux._lib.TRAVERSE_BRUTE)
+        assert max_abs_diff(a8, r.render_frame()) < 1e-13
+    assert max_abs_diff(a8, oracle_mod.Oracle(sd2, cfg8, seed=1).render_frame(threads=4)) < 1e-4
