@@ -47,7 +47,7 @@
 #define FLUX_WPE_BVH 4            // waves/SIMD of the BVH traversal kernel
 #endif
 #ifndef FLUX_BVH_REFILL_AT
-#define FLUX_BVH_REFILL_AT 16     // lanes that must be waiting for shading before the wave leaves traversal
+#define FLUX_BVH_REFILL_AT 32     // lanes that must be waiting for shading before the wave leaves traversal
 #endif
 #ifndef FLUX_WAVES_PER_EU_FAST
 #define FLUX_WAVES_PER_EU_FAST 4

@@ -6,9 +6,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VAR_DIR = os.path.join(ROOT, "flux_amd", "variants")
 VARIANTS = {
-    "f4": ["-DFLUX_WAVES_PER_EU_FAST=4"],
-    "f5": ["-DFLUX_WAVES_PER_EU_FAST=5"],
-    "f6": ["-DFLUX_WAVES_PER_EU_FAST=6"],
+    "r16": [],
+    "r8": ["-DFLUX_BVH_REFILL_AT=8"],
+    "r24": ["-DFLUX_BVH_REFILL_AT=24"],
+    "r32": ["-DFLUX_BVH_REFILL_AT=32"],
+    "r48": ["-DFLUX_BVH_REFILL_AT=48"],
+    "r16w5": ["-DFLUX_WPE_BVH=5"],
+    "r16w6": ["-DFLUX_WPE_BVH=6"],
+    "r16w3": ["-DFLUX_WPE_BVH=3"],
 }
 if "--run" not in sys.argv:
     from flux_amd import build
@@ -24,20 +29,26 @@ else:
 import sys, os, numpy as np
 sys.path.insert(0, %r)
 import flux_amd
-sd = flux_amd.load_scene(os.path.join(%r, "scenes", "demo2.yml"))
+scene = os.environ.get("SWEEP_SCENE", "demo2")
+if scene.startswith("hf:"):
+    from flux_amd.procedural import heightfield_scene
+    nx, nz = [int(x) for x in scene[3:].split("x")]
+    sd = heightfield_scene(nx, nz)
+else:
+    sd = flux_amd.load_scene(os.path.join(%r, "scenes", scene + ".yml"))
 n = int(os.environ.get("SWEEP_ROOT", "32"))
 r = flux_amd.Renderer(sd, flux_amd.JobConfiguration(n, 5, 50), seed=1)
-for v in (1, 2):
+for v in (2,):
     r.set_kernel(v)
     best = 1e9
     for _ in range(3):
         img = r.render_frame(); best = min(best, r.last_kernel_ms())
-    ref_path = "/tmp/sweep_ref_%%d.npy" %% n
+    ref_path = "/tmp/sweep_ref_%%s_%%d.npy" %% (scene.replace(":", "_"), n)
     if not os.path.exists(ref_path): np.save(ref_path, img)
     err = float(np.abs(img - np.load(ref_path)).max())
     print("  variant %%d: %%8.2f ms  %%8.1f Msamples/s  max|d| vs first = %%.3e" %% (v, best, 800*600*n*n/best/1e3, err), flush=True)
 ''' % (ROOT, ROOT)
-    for lib in sorted(glob.glob(os.path.join(VAR_DIR, "*.so")), key=lambda p: (not p.endswith("_f4.so"), p)):
+    for lib in sorted(glob.glob(os.path.join(VAR_DIR, "*.so")), key=lambda p: (not p.endswith("_r16.so"), p)):
         print(os.path.basename(lib), flush=True)
         env = dict(os.environ, FLUX_HIP_LIB=lib)
         subprocess.run([sys.executable, "-c", code], env=env, check=False)
