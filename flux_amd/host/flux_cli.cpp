@@ -149,18 +149,19 @@ int main(int argc, char **argv) {
     std::printf("Rendering %s with %d GPU worker(s), sample root %zu, depth %zu, %zu rows per work unit\n",
                 s.scene_name.c_str(), ndev, config.sample_root, config.max_depth, config.rows_per_work_unit);
 
+    // flux/src/main.rs:70-111: manager, image builder, schedule one job, wait, shut everything down
     ImageBuilder image_builder;
     image_builder.output_dir = config.outdir;
-    Job job;
-    job.id = JobID{0, 0};
-    job.scene_data = s;
-    job.config = JobConfiguration{config.sample_root, config.max_depth, config.rows_per_work_unit};
     int rc = 0;
-    try {
-        run_job(job, handles, image_builder.sender());
-    } catch (const FluxError &e) {
-        std::fprintf(stderr, "error: %s\n", e.what());
+    if (config.rows_per_work_unit == 0) {  // the reference panics in Job::work_units (job.rs:67-70)
+        std::fprintf(stderr, "error: Job row per work unit count invalid\n");
         rc = 1;
+    } else {
+        RenderManager manager(handles);
+        JobHandle job = manager.schedule_job(
+            s, JobConfiguration{config.sample_root, config.max_depth, config.rows_per_work_unit}, image_builder.sender());
+        job.wait();
+        manager.stop();
     }
     image_builder.stop();
     for (auto &w : workers) w->stop();

@@ -1,6 +1,8 @@
 // flux_host.cpp -- see flux_host.hpp.
 #include "flux_host.hpp"
 
+#include <random>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -350,6 +352,114 @@ void run_job(const Job &job, const std::vector<WorkerHandle> &workers,
     fin.kind = RenderEvent::RenderingFinished;  // manager.rs:170-185
     fin.time_s = now_s();
     events->send(fin);
+}
+
+// ---- JobIDAllocator / RenderManager: job.rs:14-34, manager.rs:72-219 ------------------------------
+JobIDAllocator::JobIDAllocator() {
+    std::random_device rd;  // rand::thread_rng().gen() (job.rs:21-24)
+    allocator_id_ = ((size_t)rd() << 32) ^ (size_t)rd();
+}
+
+RenderManager::RenderManager(std::vector<WorkerHandle> workers)
+    : workers_(std::move(workers)), queue_(std::make_shared<Channel<std::optional<ScheduledJob>>>()) {
+    if (workers_.empty())
+        throw FluxError(FLUX_E_INVALID, "RenderManager::new: must provide at least one worker handle");
+    thread_ = std::thread([this] { run(); });
+}
+
+RenderManager::~RenderManager() { stop(); }
+
+void RenderManager::stop() {  // manager.rs:215-218
+    if (stopped_) return;
+    stopped_ = true;
+    queue_->send(std::nullopt);
+    if (thread_.joinable()) thread_.join();
+}
+
+JobHandle RenderManager::schedule_job(const SceneData &scene_data, const JobConfiguration &config,
+                                      std::shared_ptr<Channel<std::optional<RenderEvent>>> result_sender) {
+    ScheduledJob sj;  // manager.rs:198-213
+    sj.job.id = ids_.next_id();
+    sj.job.scene_data = scene_data;
+    sj.job.config = config;
+    sj.notify_done = std::make_shared<Channel<int>>();
+    sj.notify_cancel = std::make_shared<Channel<int>>();
+    sj.result_sender = std::move(result_sender);
+    JobHandle h;
+    h.job_id = sj.job.id;
+    h.waiter_ = sj.notify_done;
+    h.canceller_ = sj.notify_cancel;
+    queue_->send(std::move(sj));
+    return h;
+}
+
+void RenderManager::run() {
+    // while let Ok(Some((job, notify_done, notify_cancel, result_sender))) = r.recv()   (manager.rs:83)
+    for (;;) {
+        auto msg = queue_->recv();
+        if (!msg || !*msg) break;
+        ScheduledJob sj = std::move(**msg);
+        const Job &job = sj.job;
+        RenderEvent info;
+        info.kind = RenderEvent::ImageInfo;  // manager.rs:86-98
+        info.scene_name = job.scene_data.scene_name;
+        info.width = job.scene_data.output_settings.image_width;
+        info.height = job.scene_data.output_settings.image_height;
+        if (!sj.result_sender->send(info)) continue;
+
+        auto ws = std::make_shared<Channel<WorkUnit>>(1);  // bounded(1), manager.rs:100
+        auto wg = std::make_shared<WaitGroup>();
+        std::vector<WorkUnit> units;
+        try {
+            units = job.work_units();  // the reference panics on rows_per_work_unit == 0 (job.rs:67-70)
+        } catch (const FluxError &e) {
+            std::fprintf(stderr, "RenderManager: %s\n", e.what());
+            sj.notify_done->send(0);
+            continue;
+        }
+        auto wu_queue = std::make_shared<CancellableWorkUnits>(std::move(units));
+        // cancel listener (manager.rs:105-116): ends when a cancel arrives or the job's handle side closes
+        auto cancel_ch = sj.notify_cancel;
+        std::thread cancel_listener([cancel_ch, wu_queue] {
+            if (cancel_ch->recv()) wu_queue->cancel();
+        });
+        // work-unit producer (manager.rs:118-141): blocks in send() until a worker takes the unit
+        std::thread producer([ws, wu_queue] {
+            while (auto u = wu_queue->next())
+                if (!ws->send(*u)) break;
+            ws->close();  // dropping the Sender: workers' recv() then fails and they finish the job
+        });
+
+        RenderEvent started;
+        started.kind = RenderEvent::RenderingStarted;  // manager.rs:145-154
+        started.job_id = job.id;
+        started.time_s = now_s();
+        const bool started_ok = sj.result_sender->send(started);
+        if (started_ok) {
+            auto shared_job = std::make_shared<Job>(job);
+            for (const WorkerHandle &w : workers_) {  // manager.rs:156-162
+                wg->add();
+                w.send(shared_job, ws, sj.result_sender, wg);
+            }
+            wg->wait();  // manager.rs:166
+            // every worker has dropped its Receiver: a producer still blocked in send() must fail
+            // (crossbeam: send on a channel with no receivers errors, manager.rs:131-136)
+            wu_queue->cancel();
+            ws->close();
+        } else {
+            wu_queue->cancel();
+            ws->close();
+        }
+        producer.join();
+        cancel_ch->close();  // the reference leaves the listener blocked until the JobHandle drops
+        cancel_listener.join();
+        if (!started_ok) continue;
+        RenderEvent fin;
+        fin.kind = RenderEvent::RenderingFinished;  // manager.rs:170-177
+        fin.time_s = now_s();
+        if (!sj.result_sender->send(fin)) continue;
+        sj.notify_done->send(0);  // manager.rs:179-185
+    }
 }
 
 }  // namespace flux_host

@@ -96,9 +96,18 @@ struct WorkerInfo { size_t num_threads = 0; };  // manager.rs:221-230
 template <typename T>
 class Channel {
 public:
-    void send(T v) {
-        { std::lock_guard<std::mutex> g(mu_); q_.push_back(std::move(v)); }
+    // capacity 0 = unbounded; otherwise crossbeam's bounded(cap): send blocks while the queue is full
+    explicit Channel(size_t capacity = 0) : cap_(capacity) {}
+    // returns false if the channel was closed before the value could be queued (crossbeam: send() -> Err)
+    bool send(T v) {
+        {
+            std::unique_lock<std::mutex> l(mu_);
+            if (cap_) space_.wait(l, [&] { return q_.size() < cap_ || closed_; });
+            if (closed_) return false;
+            q_.push_back(std::move(v));
+        }
         cv_.notify_one();
+        return true;
     }
     // returns nullopt once closed and drained (crossbeam: recv() -> Err)
     std::optional<T> recv() {
@@ -107,15 +116,19 @@ public:
         if (q_.empty()) return std::nullopt;
         T v = std::move(q_.front());
         q_.pop_front();
+        l.unlock();
+        space_.notify_one();
         return v;
     }
     void close() {
         { std::lock_guard<std::mutex> g(mu_); closed_ = true; }
         cv_.notify_all();
+        space_.notify_all();
     }
 private:
+    size_t cap_ = 0;
     std::mutex mu_;
-    std::condition_variable cv_;
+    std::condition_variable cv_, space_;
     std::deque<T> q_;
     bool closed_ = false;
 };
@@ -191,11 +204,74 @@ private:
     bool stopped_ = false;
 };
 
-// The part of RenderManager the CLI needs (manager.rs:83-186): ImageInfo, RenderingStarted, feed the
-// work units of one job to every worker through one shared channel, wait, RenderingFinished.
-// Cancellation and the job queue thread are out of scope.
+// One job on the calling thread, no queue and no cancellation (what the CLI's single render needs):
+// ImageInfo, RenderingStarted, all work units through one shared channel, wait, RenderingFinished.
 void run_job(const Job &job, const std::vector<WorkerHandle> &workers,
              const std::shared_ptr<Channel<std::optional<RenderEvent>>> &events);
+
+// JobIDAllocator (job.rs:14-34): allocator_id is random per allocator, ids count from 0.
+class JobIDAllocator {
+public:
+    JobIDAllocator();
+    JobID next_id() { return JobID{allocator_id_, next_++}; }
+private:
+    size_t allocator_id_ = 0, next_ = 0;
+};
+
+// CancellableIterator (manager.rs:365-393) over a job's work units: after cancel() next() yields nothing.
+class CancellableWorkUnits {
+public:
+    explicit CancellableWorkUnits(std::vector<WorkUnit> items) : items_(std::move(items)) {}
+    void cancel() { std::lock_guard<std::mutex> g(mu_); cancelled_ = true; }
+    std::optional<WorkUnit> next() {
+        std::lock_guard<std::mutex> g(mu_);
+        if (cancelled_ || pos_ >= items_.size()) return std::nullopt;
+        return items_[pos_++];
+    }
+private:
+    std::mutex mu_;
+    std::vector<WorkUnit> items_;
+    size_t pos_ = 0;
+    bool cancelled_ = false;
+};
+
+// JobHandle (manager.rs:54-70): wait() blocks until the manager has sent RenderingFinished for the job;
+// cancel() stops the hand-out of further work units (units already pulled by a worker complete).
+class JobHandle {
+public:
+    JobID job_id;
+    void wait() const { waiter_->recv(); }
+    void cancel() const { canceller_->send(0); }
+private:
+    friend class RenderManager;
+    std::shared_ptr<Channel<int>> waiter_, canceller_;
+};
+
+// RenderManager (manager.rs:30-219): a thread that takes scheduled jobs one at a time; per job it sends
+// ImageInfo, starts a producer thread that feeds the job's work units into ONE bounded(1) channel shared by
+// all workers (dynamic load balancing: a worker pulls its next unit when it is free) and a cancel-listener
+// thread, sends RenderingStarted (its timestamp precedes the fan-out, manager.rs:145), hands the job to
+// every worker, waits for the WaitGroup, sends RenderingFinished and wakes JobHandle::wait().
+class RenderManager {
+public:
+    explicit RenderManager(std::vector<WorkerHandle> workers);  // throws on an empty vector (manager.rs:74-76)
+    ~RenderManager();
+    JobHandle schedule_job(const SceneData &scene_data, const JobConfiguration &config,
+                           std::shared_ptr<Channel<std::optional<RenderEvent>>> result_sender);
+    void stop();
+private:
+    struct ScheduledJob {
+        Job job;
+        std::shared_ptr<Channel<int>> notify_done, notify_cancel;
+        std::shared_ptr<Channel<std::optional<RenderEvent>>> result_sender;
+    };
+    void run();
+    std::vector<WorkerHandle> workers_;
+    JobIDAllocator ids_;
+    std::shared_ptr<Channel<std::optional<ScheduledJob>>> queue_;
+    std::thread thread_;
+    bool stopped_ = false;
+};
 
 // SceneData -> flux_scene_desc (+ the shape storage it points to)
 struct AbiScene {

@@ -22,7 +22,8 @@ def test_host_self_test(binaries, tmp_path):
     out = subprocess.run([binaries[1], SCENES, str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "all ok" in out.stdout
-    for name in ("demo1", "demo2", "yaml errors", "work_units", "channel", "image_builder"):
+    for name in ("demo1", "demo2", "yaml errors", "work_units", "channel", "image_builder", "bounded channel",
+                 "render_manager", "cancel"):
         assert f"ok {name}" in out.stdout
 
 
