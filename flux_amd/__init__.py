@@ -6,7 +6,7 @@ built library raises ImportError: there is no CPU fallback.
 """
 from . import _lib
 from ._lib import FluxError, KERNEL_DEFAULT, KERNEL_REFILL, KERNEL_STATIC, MATH_FAST, MATH_STRICT
-from .render import Renderer, debug_fastmath, work_units, write_ppm
+from .render import Renderer, debug_fastmath, sampler_grid, work_units, write_ppm
 from .scene import (CameraData, CameraSettings, EmissiveData, GlossyReflectiveData, JobConfiguration, MatteData,
                     OutputSettings, PlaneData, ReflectiveData, SceneData, SceneError, SphereData, WorkUnit,
                     WorkUnitResult, load_scene, scene_from_dict)
@@ -15,5 +15,5 @@ __all__ = [
     "FluxError", "Renderer", "work_units", "write_ppm", "load_scene", "scene_from_dict", "SceneData", "SceneError",
     "CameraSettings", "CameraData", "OutputSettings", "SphereData", "PlaneData", "MatteData", "EmissiveData",
     "ReflectiveData", "GlossyReflectiveData", "JobConfiguration", "WorkUnit", "WorkUnitResult", "KERNEL_DEFAULT",
-    "KERNEL_STATIC", "KERNEL_REFILL", "MATH_FAST", "MATH_STRICT", "debug_fastmath",
+    "KERNEL_STATIC", "KERNEL_REFILL", "MATH_FAST", "MATH_STRICT", "debug_fastmath", "sampler_grid",
 ]

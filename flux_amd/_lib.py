@@ -17,6 +17,7 @@ SHAPE_SPHERE, SHAPE_PLANE = 0, 1
 MAT_MATTE, MAT_EMISSIVE, MAT_REFLECTIVE, MAT_GLOSSY = 0, 1, 2, 3
 KERNEL_DEFAULT, KERNEL_STATIC, KERNEL_REFILL = 0, 1, 2
 MATH_FAST, MATH_STRICT = 0, 1
+SAMPLER_REGULAR, SAMPLER_JITTERED, SAMPLER_MULTI_JITTERED, SAMPLER_CORRELATED_MULTI_JITTERED = 0, 1, 2, 3
 TABLE_PIXEL, TABLE_DISC, TABLE_HEMI = 0, 1, 2
 TRAVERSE_BVH, TRAVERSE_BRUTE = 0, 1
 NUM_STATS = 16
@@ -75,6 +76,8 @@ SYMBOLS = {
     "flux_ctx_set_kernel": (C.c_int, [_P, C.c_int]),
     "flux_ctx_set_traversal": (C.c_int, [_P, C.c_int]),
     "flux_ctx_set_math": (C.c_int, [_P, C.c_int]),
+    "flux_sampler_grid": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double)]),
     "flux_debug_fastmath": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.c_uint64]),
     "flux_ctx_bvh_info": (C.c_int, [_P, C.POINTER(C.c_uint64)]),

@@ -63,7 +63,7 @@ def build_hip(force=False, verbose=False):
 
 HOST_DIR = os.path.join(ROOT, "flux_amd", "host")
 HOST_SOURCES = ["flux_host.cpp", "yaml_lite.cpp"]
-HOST_BINARIES = {"flux": "flux_cli.cpp", "flux_host_test": "flux_host_test.cpp"}
+HOST_BINARIES = {"flux": "flux_cli.cpp", "flux_host_test": "flux_host_test.cpp", "sampler_debug": "sampler_debug.cpp"}
 
 
 def build_host(force=False, verbose=False):

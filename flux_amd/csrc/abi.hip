@@ -427,6 +427,28 @@ int flux_ctx_set_math(flux_ctx *ctx, int mode) {
     return FLUX_OK;
 }
 
+int flux_sampler_grid(int device, int kind, uint64_t sample_root, uint64_t seed, double *out_xy, double *out_hemi) {
+    if (!out_xy) return fail(FLUX_E_INVALID, "null output");
+    if (kind < FLUX_SAMPLER_REGULAR || kind > FLUX_SAMPLER_CORRELATED_MULTI_JITTERED)
+        return fail(FLUX_E_INVALID, "unknown sampler kind %d", kind);
+    if (sample_root < 1 || sample_root > 4096) return fail(FLUX_E_INVALID, "sample_root must be in [1, 4096]");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+        return fail(FLUX_E_DEVICE, "no HIP device %d (this library has no CPU fallback)", device);
+    DeviceGuard guard(device);
+    const size_t N = (size_t)sample_root * sample_root;
+    double *dxy = nullptr, *dh = nullptr;
+    hipError_t e = hipMalloc((void **)&dxy, N * 2 * sizeof(double));
+    if (e == hipSuccess && out_hemi) e = hipMalloc((void **)&dh, N * 3 * sizeof(double));
+    if (e == hipSuccess) e = flux::generate_sampler_grid(kind, seed, (uint32_t)sample_root, dxy, dh, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_xy, dxy, N * 2 * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_hemi) e = hipMemcpy(out_hemi, dh, N * 3 * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(dxy);
+    (void)hipFree(dh);
+    if (e != hipSuccess) return fail(FLUX_E_DEVICE, "sampler grid: %s", hipGetErrorString(e));
+    return FLUX_OK;
+}
+
 int flux_debug_fastmath(int device, int fn, const double *a, const double *b, double *out, uint64_t n) {
     if (!a || !out) return fail(FLUX_E_INVALID, "null argument");
     if (fn < 0 || fn > 9) return fail(FLUX_E_INVALID, "unknown function %d", fn);

@@ -11,6 +11,10 @@ namespace flux {
 hipError_t generate_tables(uint64_t seed, uint32_t S, uint32_t D, uint32_t n, uint32_t H,
                            double2 *pix, double2 *disc, double *hemi, int32_t *rowperm,
                            hipStream_t stream);
+// One set of a samplers-crate generator (0 regular, 1 jittered, 2 multi-jittered, 3 correlated MJ) and,
+// if d_hemi != nullptr, its to_hemisphere(.., 0.0) image [N][3].  Synchronises `stream`.
+hipError_t generate_sampler_grid(int kind, uint64_t seed, uint32_t n, double *d_xy, double *d_hemi,
+                                 hipStream_t stream);
 hipError_t hemi_to_aos(size_t SD, size_t N, const double *in, double *out, hipStream_t stream);
 
 // Camera::render (trace.rs:53-97).  variant: FLUX_KERNEL_STATIC / FLUX_KERNEL_REFILL;

@@ -85,6 +85,19 @@ __device__ __forceinline__ double2 to_disc(double2 p) {
     return make_double2(r * cos(phi), r * sin(phi));
 }
 
+// to_unit_hemi(p, e = 0.0): lib.rs:133-142 (what to_hemisphere(.., 0.0) applies, lib.rs:129-131)
+__device__ __forceinline__ void unit_hemi_e0(double2 q, double &ox, double &oy, double &oz) {
+    double cos_phi = cos(2.0 * kPi * q.x);
+    double sin_phi = sin(2.0 * kPi * q.x);
+    double cos_theta = pow(1.0 - q.y, 1.0 / (0.0 + 1.0));
+    double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+    double pu = sin_theta * cos_phi, pv = sin_theta * sin_phi, pw = cos_theta;
+    double len = sqrt(pu * pu + pv * pv + pw * pw);
+    ox = pu / len;
+    oy = pv / len;
+    oz = pw / len;
+}
+
 // pixel_sets (sampling.rs:16-17) and disc_sets (sampling.rs:19-21)
 __global__ void cmj_fill_kernel(uint64_t seed, uint64_t kind, uint32_t S, uint32_t n,
                                 const uint16_t *__restrict__ perms, double2 *__restrict__ out) {
@@ -115,17 +128,12 @@ __global__ void hemi_fill_kernel(uint64_t seed, uint32_t S, uint32_t D, uint32_t
     uint32_t yk = pb[(size_t)i * n + k];        // y-shuffle of row i, element k
     uint32_t xi = pb[((size_t)n + k) * n + i];  // x-shuffle of column k, element i
     double2 q = mj_point(stream_key(seed, kKindHemi, s, d, kSubJitter), n, i, k, xi, yk);
-    // to_unit_hemi(p, e = 0.0): lib.rs:133-142
-    double cos_phi = cos(2.0 * kPi * q.x);
-    double sin_phi = sin(2.0 * kPi * q.x);
-    double cos_theta = pow(1.0 - q.y, 1.0 / (0.0 + 1.0));
-    double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
-    double pu = sin_theta * cos_phi, pv = sin_theta * sin_phi, pw = cos_theta;
-    double len = sqrt(pu * pu + pv * pv + pw * pw);
+    double pu, pv, pw;
+    unit_hemi_e0(q, pu, pv, pw);
     double *o = out + sd * 3 * N;
-    o[p] = pu / len;
-    o[N + p] = pv / len;
-    o[2 * N + p] = pw / len;
+    o[p] = pu;
+    o[N + p] = pv;
+    o[2 * N + p] = pw;
 }
 
 // SoA [S][D][3][N] -> reference order [S][D][N][3] (introspection only)
@@ -140,7 +148,56 @@ __global__ void hemi_to_aos_kernel(size_t SD, size_t N, const double *__restrict
     out[t * 3 + 2] = b[2 * N + p];
 }
 
+// One set of any of the samplers crate's four generators (sampler-debug/src/main.rs:48-57) and, optionally,
+// its to_hemisphere(.., 0.0) image: kind 0 grid_regular (lib.rs:184-191), 1 grid_jittered (lib.rs:35-44),
+// 2 grid_multi_jittered (= hemi stream, set 0, depth 0), 3 grid_correlated_multi_jittered (= pixel stream, set 0).
+__global__ void sampler_grid_kernel(int kind, uint64_t seed, uint32_t n, const uint16_t *__restrict__ perms,
+                                    double *__restrict__ out_xy, double *__restrict__ out_hemi) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t N = n * n;
+    if (p >= N) return;
+    const uint32_t i = p / n, k = p % n;
+    double2 q;
+    if (kind <= 1) {
+        const double increment = 1.0 / (double)n;
+        const double start = 0.5 * increment;
+        q = make_double2(start + increment * (double)i, start + increment * (double)k);
+        if (kind == 1) {
+            const uint64_t key = stream_key(seed, kKindDebugJitter, 0, 0, 0);
+            q.x = q.x + (unit(key, 2ull * p) - 0.5) * increment;
+            q.y = q.y + (unit(key, 2ull * p + 1ull) - 0.5) * increment;
+        }
+    } else if (kind == 2) {
+        const uint32_t yk = perms[(size_t)i * n + k];
+        const uint32_t xi = perms[((size_t)n + k) * n + i];
+        q = mj_point(stream_key(seed, kKindHemi, 0, 0, kSubJitter), n, i, k, xi, yk);
+    } else {
+        q = mj_point(stream_key(seed, kKindPixel, 0, 0, kSubJitter), n, i, k, perms[i], perms[n + k]);
+    }
+    out_xy[2 * (size_t)p] = q.x;
+    out_xy[2 * (size_t)p + 1] = q.y;
+    if (out_hemi) unit_hemi_e0(q, out_hemi[3 * (size_t)p], out_hemi[3 * (size_t)p + 1], out_hemi[3 * (size_t)p + 2]);
+}
+
 static inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+hipError_t generate_sampler_grid(int kind, uint64_t seed, uint32_t n, double *d_xy, double *d_hemi,
+                                 hipStream_t stream) {
+    uint16_t *perms = nullptr;
+    hipError_t e = hipSuccess;
+    if (kind == 2) {
+        if ((e = hipMalloc(&perms, (size_t)2 * n * n * sizeof(uint16_t))) != hipSuccess) return e;
+        mj_perm_kernel<<<blocks_for((size_t)2 * n, 64), 64, 0, stream>>>(seed, 1, 1, n, perms);
+    } else if (kind == 3) {
+        if ((e = hipMalloc(&perms, (size_t)2 * n * sizeof(uint16_t))) != hipSuccess) return e;
+        cmj_perm_kernel<<<1, 64, 0, stream>>>(seed, kKindPixel, 1, n, perms);
+    }
+    sampler_grid_kernel<<<blocks_for((size_t)n * n, 256), 256, 0, stream>>>(kind, seed, n, perms, d_xy, d_hemi);
+    e = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(stream);
+    (void)hipFree(perms);
+    return e != hipSuccess ? e : e2;
+}
 
 hipError_t generate_tables(uint64_t seed, uint32_t S, uint32_t D, uint32_t n, uint32_t H,
                            double2 *pix, double2 *disc, double *hemi, int32_t *rowperm,

@@ -166,3 +166,14 @@ def debug_fastmath(fn: int, a, b=None, device: int = 0) -> np.ndarray:
         pb = b.ctypes.data_as(C.POINTER(C.c_double))
     _lib.check(_lib.lib.flux_debug_fastmath(device, fn, pa, pb, out.ctypes.data_as(C.POINTER(C.c_double)), a.size))
     return out
+
+
+def sampler_grid(kind: int, sample_root: int, seed: int = 1, hemi: bool = False, device: int = 0):
+    """One set of a samplers-crate generator computed on the device (include/flux_abi.h flux_sampler_grid):
+    (n*n, 2) array, plus its to_hemisphere(.., 0.0) image (n*n, 3) when hemi=True."""
+    n2 = sample_root * sample_root
+    xy = np.empty((n2, 2), dtype=np.float64)
+    hm = np.empty((n2, 3), dtype=np.float64) if hemi else None
+    _lib.check(_lib.lib.flux_sampler_grid(device, kind, sample_root, seed, xy.ctypes.data_as(C.POINTER(C.c_double)),
+                                          hm.ctypes.data_as(C.POINTER(C.c_double)) if hemi else None))
+    return (xy, hm) if hemi else xy

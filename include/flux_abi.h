@@ -218,6 +218,18 @@ int flux_ctx_camera_basis(flux_ctx *ctx, double uvw[9]); /* CameraBasis::new sce
 /* bytes of HBM held by the context's tables + scene */
 uint64_t flux_ctx_device_bytes(flux_ctx *ctx);
 
+/* The samplers crate's four generators, evaluated on the device (what sampler-debug plots,
+ * sampler-debug/src/main.rs:48-57): kind 0 grid_regular (samplers/src/lib.rs:184-191), 1 grid_jittered
+ * (lib.rs:35-44), 2 grid_multi_jittered (lib.rs:64-73; equals hemi-stream set 0 depth 0 before the
+ * hemisphere map), 3 grid_correlated_multi_jittered (lib.rs:75-90; equals pixel_sets[0]).  Writes
+ * sample_root^2 (x,y) pairs to out_xy and, if out_hemi != NULL, to_hemisphere(.., 0.0) of them
+ * (lib.rs:129-142) as sample_root^2 (x,y,z) triples.  Host pointers. */
+#define FLUX_SAMPLER_REGULAR 0
+#define FLUX_SAMPLER_JITTERED 1
+#define FLUX_SAMPLER_MULTI_JITTERED 2
+#define FLUX_SAMPLER_CORRELATED_MULTI_JITTERED 3
+int flux_sampler_grid(int device, int kind, uint64_t sample_root, uint64_t seed, double *out_xy, double *out_hemi);
+
 /* Test hook for csrc/flux_math.h: out[i] = fn(a[i], b[i]) evaluated ON THE DEVICE (host pointers in,
  * host pointer out; b may be NULL for unary functions).  fn: 0 frsqrt, 1 fsqrt, 2 fdiv, 3 flog2,
  * 4 fexp2, 5 fpow_pos, 6 sin(2 pi a), 7 cos(2 pi a), 8 raw v_rsq_f64, 9 raw v_rcp_f64. */
