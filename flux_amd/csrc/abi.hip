@@ -354,7 +354,7 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
 
     // ---- HBM allocations ------------------------------------------------------
     const size_t pix_bytes = (size_t)c->S * c->N * sizeof(double2);
-    const size_t hemi_bytes = (size_t)c->S * c->D * c->N * 3 * sizeof(double);
+    const size_t hemi_bytes = (size_t)c->S * c->D * c->N * flux::kHemiDoubles * sizeof(double);
     const size_t perm_bytes = (size_t)c->H * c->S * sizeof(int32_t);
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) {

@@ -6,8 +6,14 @@
 
 #include "flux_bvh.h"
 
+// hemi_sets layout: 1 = [S][D][N][4] (x,y,z,pad: one aligned 32-B sector per sample), 0 = [S][D][3][N] planes
+#ifndef FLUX_HEMI_AOS4
+#define FLUX_HEMI_AOS4 1
+#endif
+
 namespace flux {
 
+constexpr int kHemiDoubles = FLUX_HEMI_AOS4 ? 4 : 3;  // doubles of hemi table per (set, depth, sample)
 constexpr double kTMin = 0.0005;                       // constants.rs:4
 constexpr double kPi = 3.14159265358979323846264338327950288;
 constexpr double kInvPi = 1.0 / kPi;                   // constants.rs:5
@@ -98,7 +104,7 @@ struct RenderParams {
     const DevMaterial *mats;
     const double2 *pix;   // [S][N] (x,y)                 pixel_sets
     const double2 *disc;  // [S][N] (x,y)                 disc_sets
-    const double *hemi;   // [S][D][3][N] SoA x|y|z planes hemi_sets
+    const double *hemi;   // hemi_sets: [S][D][N][4] (x,y,z,pad) -- or [S][D][3][N] planes with FLUX_HEMI_AOS4=0
     const int32_t *rowperm;  // [H][S] sample-set index per (row, col)
     // work: rows first_row + k*row_stride, k < num_rows
     double *out;          // [num_rows][W][3]
