@@ -155,8 +155,8 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     if (cfg->sample_root < 1 || cfg->sample_root > 4096)
         return fail(FLUX_E_INVALID, "sample_root must be in [1,4096], got %llu",
                     (unsigned long long)cfg->sample_root);
-    if (cfg->max_trace_depth < 1 || cfg->max_trace_depth > 16)
-        return fail(FLUX_E_INVALID, "max_trace_depth must be in [1,16], got %llu",
+    if (cfg->max_trace_depth < 1 || cfg->max_trace_depth > 256)
+        return fail(FLUX_E_INVALID, "max_trace_depth must be in [1,256], got %llu",
                     (unsigned long long)cfg->max_trace_depth);
     if (scene->image_width < 1 || scene->image_height < 1 || scene->image_width > 65535 ||
         scene->image_height > (1u << 20))
@@ -493,6 +493,10 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
     p.num_rows = (int32_t)num_rows;
     p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
+    // STRICT keeps the (f,s) recursion stack in LDS: 4 doubles per level per lane, 64-thread blocks
+    if (ctx->math == FLUX_MATH_STRICT && (size_t)ctx->D * 4 * 64 * sizeof(double) > 60 * 1024)
+        return fail(FLUX_E_INVALID, "max_trace_depth %u needs %zu B of LDS per block in FLUX_MATH_STRICT (limit 60 KiB); "
+                    "use FLUX_MATH_FAST", ctx->D, (size_t)ctx->D * 4 * 64 * sizeof(double));
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
     HIP_TRY(hipEventRecord(ctx->ev1, stream));

@@ -155,6 +155,21 @@ def test_reflective_and_tie_break(flux, oracle_mod, demo1, math):
     r.close()
 
 
+def test_deep_paths(flux, oracle_mod, demo1):
+    """max_trace_depth far beyond the default: FAST has no per-depth on-chip state; STRICT's LDS recursion
+    stack has a documented limit and fails loudly beyond it."""
+    sd = small_scene(demo1, 16, 12)
+    r, o = _pair(flux, oracle_mod, sd, 4, D=40, math="fast")
+    assert max_abs_diff(r.render_frame(), o.render_frame(threads=4)) < TOL_IMAGE
+    r.set_math(flux.MATH_STRICT)
+    with pytest.raises(flux.FluxError):
+        r.render_frame()
+    r.close()
+    r, o = _pair(flux, oracle_mod, sd, 4, D=24, math="strict")
+    assert max_abs_diff(r.render_frame(), o.render_frame(threads=4)) < TOL_IMAGE
+    r.close()
+
+
 def test_abi_errors(flux, demo1):
     sd = small_scene(demo1, 16, 8)
     with pytest.raises(flux.FluxError):
