@@ -58,7 +58,7 @@ def test_product_never_touches_the_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, "flux_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".inc", ".cpp", ".c")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 if re.search(r"\boracle\b|fxo_", text):
                     bad.append(os.path.join(dirpath, f))
