@@ -246,6 +246,29 @@ void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &
     } else {
         B.build_inner(0, (uint32_t)tris.size(), 0);
     }
+    // Relabel the nodes breadth-first with siblings adjacent (built depth-first: child0 = parent + 1, child1
+    // far away): the two children of a node then share one 128-B line, and the top of the tree -- touched by
+    // every ray -- is one contiguous, cache-resident block.
+    if (nodes.size() > 1) {
+        std::vector<int32_t> order_bfs;
+        order_bfs.reserve(nodes.size());
+        order_bfs.push_back(0);
+        for (size_t head = 0; head < order_bfs.size(); head++) {
+            const DevNode &N = nodes[(size_t)order_bfs[head]];
+            if (N.child0 >= 0) order_bfs.push_back(N.child0);
+            if (N.child1 >= 0) order_bfs.push_back(N.child1);
+        }
+        std::vector<int32_t> new_index(nodes.size(), -1);
+        for (size_t k = 0; k < order_bfs.size(); k++) new_index[(size_t)order_bfs[k]] = (int32_t)k;
+        std::vector<DevNode> re(nodes.size());
+        for (size_t k = 0; k < order_bfs.size(); k++) {
+            DevNode N = nodes[(size_t)order_bfs[k]];
+            if (N.child0 >= 0) N.child0 = new_index[(size_t)N.child0];
+            if (N.child1 >= 0) N.child1 = new_index[(size_t)N.child1];
+            re[k] = N;
+        }
+        nodes.swap(re);
+    }
     std::vector<DevTri> sorted(tris.size());
     for (size_t k = 0; k < tris.size(); k++) sorted[k] = tris[B.order[k]];
     tris.swap(sorted);
