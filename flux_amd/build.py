@@ -62,8 +62,9 @@ def build_hip(force=False, verbose=False):
 
 
 HOST_DIR = os.path.join(ROOT, "flux_amd", "host")
-HOST_SOURCES = ["flux_host.cpp", "yaml_lite.cpp"]
-HOST_BINARIES = {"flux": "flux_cli.cpp", "flux_host_test": "flux_host_test.cpp", "sampler_debug": "sampler_debug.cpp"}
+HOST_SOURCES = ["flux_host.cpp", "yaml_lite.cpp", "cbor.cpp", "flux_net.cpp"]
+HOST_BINARIES = {"flux": "flux_cli.cpp", "flux_host_test": "flux_host_test.cpp", "sampler_debug": "sampler_debug.cpp",
+                 "flux_node": "flux_node.cpp"}
 
 
 def build_host(force=False, verbose=False):
@@ -71,7 +72,7 @@ def build_host(force=False, verbose=False):
     build_hip(force=False, verbose=verbose)
     outs = []
     common = [os.path.join(HOST_DIR, s) for s in HOST_SOURCES]
-    hdrs = [os.path.join(HOST_DIR, h) for h in ("flux_host.hpp", "yaml_lite.hpp")] + [os.path.join(ROOT, "include", "flux_abi.h")]
+    hdrs = [os.path.join(HOST_DIR, h) for h in ("flux_host.hpp", "yaml_lite.hpp", "cbor.hpp", "flux_net.hpp")] + [os.path.join(ROOT, "include", "flux_abi.h")]
     for name, main in HOST_BINARIES.items():
         out = os.path.join(HOST_DIR, name)
         src = [os.path.join(HOST_DIR, main)] + common

@@ -3,8 +3,9 @@
 // Mirrors flux/src/main.rs: config_from_args (:126-205; same flags, same defaults: root 1, depth 5,
 // 50 rows per work unit), load YAML -> SceneData (:27-29), start workers (:37-70), schedule one job and
 // wait (:92-94), ImageBuilder writes "<scene_name>.ppm" into the cwd and prints the total time
-// (manager.rs:326-335).  Additions: --seed (the reference seeds from OS entropy), --gpus, --outdir.
-// Not carried over: -n/--node (CBOR/TCP render nodes) and -g (SDL preview) -- out of scope, rejected.
+// (manager.rs:326-335).  -n/--node ADDRESS[:PORT] adds NetworkWorkers (flux_node processes, flux_net.hpp) and
+// -L leaves the local GPUs out, as in main.rs:37-66.  Additions: --seed (the reference seeds from OS
+// entropy), --gpus, --outdir.  Not carried over: -g (SDL preview), rejected.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,6 +14,7 @@
 #include <vector>
 
 #include "flux_host.hpp"
+#include "flux_net.hpp"
 
 using namespace flux_host;
 
@@ -39,10 +41,10 @@ struct Config {  // flux/src/main.rs:115-124
 void usage() {
     std::fprintf(stderr,
                  "flux (MI355X render path)\n\nUSAGE:\n    flux [FLAGS] [OPTIONS] <scene_file>\n\nFLAGS:\n"
-                 "    -L               Do not use the local host for rendering (accepted; there is no CPU worker)\n"
+                 "    -L               Do not use the local host (its GPUs) for rendering\n"
                  "    -g               Show a live graphical preview window during rendering (not supported)\n\nOPTIONS:\n"
                  "    -d, --depth <DEPTH>          Tracing depth [default 5]\n"
-                 "    -n, --node <ADDRESS[:PORT]>  Render using a flux-node process (not supported)\n"
+                 "    -n, --node <ADDRESS[:PORT]>  Render using the flux_node process at this address (repeatable)\n"
                  "    -R, --rows <COUNT>           Image rows per work unit [default 50]\n"
                  "    -r, --root <ROOT>            Sample root [default 1]\n"
                  "    -t, --threads <N>            CPU rendering threads (accepted, unused)\n"
@@ -118,10 +120,6 @@ Config config_from_args(int argc, char **argv) {
 
 int main(int argc, char **argv) {
     Config config = config_from_args(argc, argv);
-    if (!config.network_workers.empty()) {
-        std::fprintf(stderr, "error: -n/--node: network render nodes are not part of the MI355X render path\n");
-        return 2;
-    }
     if (config.show_live_preview) {
         std::fprintf(stderr, "error: -g: the SDL live preview is not part of the MI355X render path\n");
         return 2;
@@ -133,21 +131,36 @@ int main(int argc, char **argv) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;
     }
-    int ndev = flux_device_count();
-    if (ndev < 1) {
+    // main.rs:37-66: the local worker(s) unless -L, then one NetworkWorker per -n
+    int ndev = config.use_local_worker ? flux_device_count() : 0;
+    if (config.use_local_worker && ndev < 1) {
         std::fprintf(stderr, "error: no HIP device visible (this renderer has no CPU fallback)\n");
         return 1;
     }
     if (config.gpus > 0 && config.gpus < ndev) ndev = config.gpus;
 
-    std::vector<std::unique_ptr<GpuWorker>> workers;
+    std::vector<std::unique_ptr<Worker>> workers;
     std::vector<WorkerHandle> handles;
     for (int d = 0; d < ndev; d++) {
         workers.emplace_back(new GpuWorker(d, config.seed));
         handles.push_back(workers.back()->handle());
     }
-    std::printf("Rendering %s with %d GPU worker(s), sample root %zu, depth %zu, %zu rows per work unit\n",
-                s.scene_name.c_str(), ndev, config.sample_root, config.max_depth, config.rows_per_work_unit);
+    for (const std::string &endpoint : config.network_workers) {
+        std::printf("Connecting to worker %s\n", endpoint.c_str());
+        try {
+            workers.emplace_back(new NetworkWorker(endpoint));
+        } catch (const FluxError &e) {
+            std::fprintf(stderr, "Error connecting to %s: %s\n", endpoint.c_str(), e.what());  // main.rs:60-63
+            return 1;
+        }
+        handles.push_back(workers.back()->handle());
+    }
+    if (handles.empty()) {
+        std::fprintf(stderr, "No workers specified, exiting\n");  // main.rs:68-71
+        return 1;
+    }
+    std::printf("Rendering %s with %d GPU worker(s) and %zu network node(s), sample root %zu, depth %zu, %zu rows per work unit\n",
+                s.scene_name.c_str(), ndev, config.network_workers.size(), config.sample_root, config.max_depth, config.rows_per_work_unit);
 
     // flux/src/main.rs:70-111: manager, image builder, schedule one job, wait, shut everything down
     ImageBuilder image_builder;

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "flux_host.hpp"
+#include "flux_net.hpp"
 #include "yaml_lite.hpp"
 
 using namespace flux_host;
@@ -332,6 +333,250 @@ int main(int argc, char **argv) {
         mgr2.stop();
         q.stop();
         std::puts("ok cancel");
+    }
+    {
+        // CBOR codec against the RFC 8949 Appendix A examples (published test vectors of the format)
+        auto hex = [](const std::string &b) {
+            static const char *d = "0123456789abcdef";
+            std::string h;
+            for (unsigned char c : b) { h.push_back(d[c >> 4]); h.push_back(d[c & 15]); }
+            return h;
+        };
+        auto unhex = [](const std::string &h) {
+            std::string b;
+            for (size_t k = 0; k + 1 < h.size(); k += 2) b.push_back((char)std::stoi(h.substr(k, 2), nullptr, 16));
+            return b;
+        };
+        struct U { uint64_t v; const char *h; } us[] = {{0, "00"}, {1, "01"}, {10, "0a"}, {23, "17"}, {24, "1818"},
+            {25, "1819"}, {100, "1864"}, {1000, "1903e8"}, {1000000, "1a000f4240"}, {1000000000000ull, "1b000000e8d4a51000"},
+            {18446744073709551615ull, "1bffffffffffffffff"}};
+        for (auto &u : us) {
+            cbor::Encoder e;
+            e.uint(u.v);
+            CHECK(hex(e.out) == u.h);
+            std::string raw = unhex(u.h);
+            cbor::StringReader r(raw);
+            cbor::Decoder d(r);
+            uint64_t got = 1;
+            CHECK(d.read_uint(got) && got == u.v && r.at_end());
+        }
+        struct I { int64_t v; const char *h; } is[] = {{-1, "20"}, {-10, "29"}, {-100, "3863"}, {-1000, "3903e7"}};
+        for (auto &i : is) {
+            cbor::Encoder e;
+            e.integer(i.v);
+            CHECK(hex(e.out) == i.h);
+            std::string raw = unhex(i.h);
+            cbor::StringReader r(raw);
+            cbor::Decoder d(r);
+            int64_t got = 0;
+            CHECK(d.read_int(got) && got == i.v);
+        }
+        // floats: the RFC's examples are the shortest exact encodings, which is serde_cbor's f64 rule
+        struct F { double v; const char *h; } fs[] = {{0.0, "f90000"}, {-0.0, "f98000"}, {1.0, "f93c00"}, {1.1, "fb3ff199999999999a"},
+            {1.5, "f93e00"}, {65504.0, "f97bff"}, {100000.0, "fa47c35000"}, {3.4028234663852886e+38, "fa7f7fffff"},
+            {1.0e+300, "fb7e37e43c8800759c"}, {5.960464477539063e-8, "f90001"}, {0.00006103515625, "f90400"}, {-4.0, "f9c400"},
+            {-4.1, "fbc010666666666666"}, {INFINITY, "f97c00"}, {-INFINITY, "f9fc00"}};
+        for (auto &f : fs) {
+            cbor::Encoder e;
+            e.real(f.v);
+            CHECK(hex(e.out) == f.h);
+            std::string raw = unhex(f.h);
+            cbor::StringReader r(raw);
+            cbor::Decoder d(r);
+            double got = 7;
+            CHECK(d.read_number(got) && got == f.v && std::signbit(got) == std::signbit(f.v));
+        }
+        {
+            cbor::Encoder e;
+            e.real(NAN);
+            CHECK(hex(e.out) == "f97e00");
+            for (const char *h : {"f97e00", "fa7fc00000", "fb7ff8000000000000", "fa7f800000", "fb7ff0000000000000"}) {
+                std::string raw = unhex(h);
+                cbor::StringReader r(raw);
+                cbor::Decoder d(r);
+                double got = 0;
+                CHECK(d.read_number(got) && (std::isnan(got) || std::isinf(got)));
+            }
+        }
+        {   // simple values, strings, arrays, maps: definite (encoder) and indefinite (decoder only)
+            cbor::Encoder e;
+            e.boolean(false); e.boolean(true); e.null(); e.text(""); e.text("a"); e.text("IETF"); e.text("\xc3\xbc");
+            e.array(0); e.array(3); e.uint(1); e.uint(2); e.uint(3);
+            e.map(2); e.text("a"); e.uint(1); e.text("b"); e.array(2); e.uint(2); e.uint(3);
+            CHECK(hex(e.out) == "f4f5f660616164494554466" "2c3bc80830102" "03a26161016162820203");
+            cbor::Encoder big;
+            big.array(25);
+            for (int k = 1; k <= 25; k++) big.uint((uint64_t)k);
+            CHECK(hex(big.out) == "98190102030405060708090a0b0c0d0e0f101112131415161718181819");
+            // {"a": 1, "b": [2, 3]} definite, then {_ "a": 1, "b": [_ 2, 3]} and (_ "strea", "ming") indefinite, tag 1
+            std::string raw = unhex("a26161016162820203" "bf61610161629f0203ffff" "7f657374726561646d696e67ff" "c11a514b67b0" "f7");
+            cbor::StringReader r(raw);
+            cbor::Decoder d(r);
+            for (int rep = 0; rep < 2; rep++) {
+                uint64_t n, m, v;
+                std::string k;
+                CHECK(d.read_map(n) && (rep == 0 ? n == 2 : n == cbor::Decoder::kIndefinite));
+                CHECK((rep == 0 || !d.at_break()) && d.read_text(k) && k == "a" && d.read_uint(v) && v == 1);
+                CHECK((rep == 0 || !d.at_break()) && d.read_text(k) && k == "b" && d.read_array(m));
+                CHECK((rep == 0 || !d.at_break()) && d.read_uint(v) && v == 2 && d.read_uint(v) && v == 3);
+                if (rep == 1) CHECK(d.at_break() && d.at_break());
+            }
+            std::string st;
+            CHECK(d.read_text(st) && st == "streaming");
+            uint64_t tagged = 0;
+            CHECK(d.read_uint(tagged) && tagged == 1363896240);  // tag 1 is skipped
+            CHECK(d.read_null());                                // undefined reads as null
+            CHECK(d.peek() == cbor::Type::End && !d.failed());
+            std::string raw2 = unhex("a26161016162820203" "9f018202039f0405ffff" "5f42010243030405ff" "18");
+            cbor::StringReader r2(raw2);
+            cbor::Decoder d2(r2);
+            CHECK(d2.skip() && d2.skip() && d2.skip());          // whole items of every container flavour
+            CHECK(!d2.skip() && d2.failed());                    // truncated head
+        }
+        std::puts("ok cbor");
+    }
+    {
+        // node-protocol messages: serde_cbor 0.9 layout on the way out, both enum layouts on the way in
+        auto hex = [](const std::string &b) {
+            static const char *d = "0123456789abcdef";
+            std::string h;
+            for (unsigned char c : b) { h.push_back(d[c >> 4]); h.push_back(d[c & 15]); }
+            return h;
+        };
+        cbor::Encoder e0;
+        encode_worker_info(e0, WorkerInfo{16});
+        CHECK(hex(e0.out) == "a1" "6b6e756d5f74687265616473" "10");  // {"num_threads": 16}
+        NetworkWorkerRequest done;
+        cbor::Encoder e1;
+        encode_request(e1, done);
+        CHECK(hex(e1.out) == "64446f6e65");                           // "Done"
+        NetworkWorkerRequest wu;
+        wu.kind = NetworkWorkerRequest::WorkUnitMsg;
+        wu.unit = WorkUnit{50, 99, JobID{7, 3}};
+        cbor::Encoder e2;
+        encode_request(e2, wu);
+        // ["WorkUnit", {"row_start": 50, "row_end": 99, "job_id": [7, 3]}]
+        CHECK(hex(e2.out) == "82" "68576f726b556e6974" "a3" "69726f775f7374617274" "1832" "67726f775f656e64" "1863"
+                             "666a6f625f6964" "820703");
+        SceneData sd = scene_from_yaml_file(scenes + "/demo2.yml");
+        NetworkWorkerRequest set;
+        set.kind = NetworkWorkerRequest::SetJob;
+        set.job.id = JobID{123456789012345ull, 2};
+        set.job.scene_data = sd;
+        set.job.config = JobConfiguration{128, 5, 50};
+        cbor::Encoder e3;
+        encode_request(e3, set);
+        {
+            cbor::StringReader r(e3.out);
+            cbor::Decoder d(r);
+            NetworkWorkerRequest back;
+            CHECK(decode_request(d, back) && r.at_end() && back.kind == NetworkWorkerRequest::SetJob);
+            CHECK(back.job.id.allocator_id == 123456789012345ull && back.job.id.id == 2 && back.job.config.sample_root == 128);
+            const SceneData &b = back.job.scene_data;
+            CHECK(b.scene_name == "demo2" && b.shapes.size() == 13 && b.camera_data.lens_radius == 0.09);
+            CHECK(b.output_settings.image_width == 800 && b.output_settings.pixel_size == 0.5 && b.camera_settings.eye.y == 5.5);
+            for (size_t k = 0; k < 13; k++) CHECK(b.shapes[k].index() == sd.shapes[k].index());
+            auto *s1 = std::get_if<SphereData>(&b.shapes[1]);
+            CHECK(s1 && s1->center.x == -9.0 && s1->radius == 5.0 && !s1->invert && std::get<EmissiveData>(s1->material).power == 10.0);
+            auto *g = std::get_if<GlossyReflectiveData>(&std::get<SphereData>(b.shapes[2]).material);
+            CHECK(g && g->reflect_exponent == 10000.0 && g->reflect_color.g == 0.6 && g->reflect_amount == 0.5);
+            auto *pl = std::get_if<PlaneData>(&b.shapes[12]);
+            CHECK(pl && pl->normal.y == 1.0 && std::get<MatteData>(pl->material).diffuse_coefficient == 1.0);
+            CHECK(std::get<SphereData>(b.shapes[0]).invert);
+        }
+        // the same request in the serde_cbor >= 0.10 layout ({"WorkUnit": {...}}) and with an unknown field
+        {
+            cbor::Encoder e;
+            e.map(1); e.text("WorkUnit"); e.map(4); e.key("row_start"); e.uint(1); e.key("extra"); e.array(2); e.uint(1); e.uint(2);
+            e.key("row_end"); e.uint(2); e.key("job_id"); e.array(2); e.uint(5); e.uint(6);
+            cbor::StringReader r(e.out);
+            cbor::Decoder d(r);
+            NetworkWorkerRequest back;
+            CHECK(decode_request(d, back) && back.kind == NetworkWorkerRequest::WorkUnitMsg && back.unit.row_end == 2 && back.unit.job_id.id == 6);
+            std::string bad = "\x82\x65Other\x01";
+            cbor::StringReader rb(bad);
+            cbor::Decoder db(rb);
+            CHECK(!decode_request(db, back));  // unknown variant
+        }
+        RenderEvent ev;
+        ev.kind = RenderEvent::RowsReady;
+        ev.result.work_unit = WorkUnit{3, 4, JobID{1, 0}};
+        ev.result.rows = {{Color{1.0, 0.5, 0.0}, Color{0.1, 0.2, 0.3}}, {Color{0.0, 0.0, 0.0}, Color{1e-300, 0.25, 0.999}}};
+        cbor::Encoder e4;
+        encode_event(e4, ev);
+        CHECK(hex(e4.out).substr(0, 22) == "8269526f77735265616479");  // ["RowsReady", ...
+        RenderEvent st;
+        st.kind = RenderEvent::RenderingStarted;
+        st.job_id = JobID{9, 1};
+        st.time_s = 1538352000.25;
+        encode_event(e4, st);
+        RenderEvent ii;
+        ii.kind = RenderEvent::ImageInfo;
+        ii.scene_name = "demo2";
+        ii.width = 800;
+        ii.height = 600;
+        encode_event(e4, ii);
+        RenderEvent fin;
+        fin.kind = RenderEvent::RenderingFinished;
+        fin.time_s = 1538352010.5;
+        encode_event(e4, fin);
+        {
+            cbor::StringReader r(e4.out);  // a stream of concatenated values, as StreamDeserializer reads it
+            cbor::Decoder d(r);
+            RenderEvent a, b, c, f;
+            CHECK(decode_event(d, a) && decode_event(d, b) && decode_event(d, c) && decode_event(d, f) && d.peek() == cbor::Type::End);
+            CHECK(a.kind == RenderEvent::RowsReady && a.result.work_unit.row_end == 4 && a.result.rows.size() == 2);
+            CHECK(a.result.rows[0][1].g == 0.2 && a.result.rows[1][1].r == 1e-300 && a.result.rows[1][1].b == 0.999);
+            CHECK(b.kind == RenderEvent::RenderingStarted && b.job_id.allocator_id == 9 && std::fabs(b.time_s - 1538352000.25) < 1e-6);
+            CHECK(c.kind == RenderEvent::ImageInfo && c.scene_name == "demo2" && c.width == 800 && c.height == 600);
+            CHECK(f.kind == RenderEvent::RenderingFinished && std::fabs(f.time_s - 1538352010.5) < 1e-6);
+        }
+        std::puts("ok node messages");
+    }
+    {
+        // loopback: RenderManager -> NetworkWorker -> TCP -> NodeServer -> (fake) worker and back
+        FakeWorker backend(7, 1);
+        NodeServer server("127.0.0.1", "0", backend.handle(), 3);
+        std::thread srv([&] { server.serve_forever(); });
+        const std::string endpoint = "127.0.0.1:" + std::to_string(server.port());
+        {
+            NetworkWorker nw(endpoint);
+            CHECK(nw.info().num_threads == 3);
+            FakeWorker local(1, 1);
+            RenderManager mgr({nw.handle(), local.handle()});
+            SceneData sd = scene_from_yaml_file(scenes + "/demo1.yml");
+            sd.output_settings.image_width = 5;
+            auto ev = std::make_shared<Channel<std::optional<RenderEvent>>>();
+            JobHandle h = mgr.schedule_job(sd, JobConfiguration{2, 5, 25}, ev);
+            h.wait();
+            auto e = drain(ev);
+            CHECK(e.size() == 2 + 24 + 1 && e.back().kind == RenderEvent::RenderingFinished);
+            std::set<size_t> starts;
+            size_t remote = 0;
+            for (size_t k = 2; k + 1 < e.size(); k++) {
+                CHECK(e[k].kind == RenderEvent::RowsReady && e[k].result.rows.size() == 25 && e[k].result.rows[0].size() == 5);
+                CHECK(starts.insert(e[k].result.work_unit.row_start).second);
+                CHECK(e[k].result.work_unit.job_id.id == h.job_id.id);
+                if (e[k].result.rows[0][0].r == 7.0) remote++;   // rendered by the node's worker
+                else CHECK(e[k].result.rows[0][0].r == 1.0);
+            }
+            CHECK(starts.size() == 24 && remote >= 2 && remote == (size_t)backend.units_done && backend.jobs_seen == 1);
+            mgr.stop();
+            nw.stop();
+            local.stop();
+        }
+        while (server.clients_served() < 1) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        bool refused = false;
+        try {
+            NetworkWorker nobody("127.0.0.1:1");
+        } catch (const FluxError &) {
+            refused = true;
+        }
+        CHECK(refused);
+        server.stop();
+        srv.join();
+        backend.stop();
+        std::puts("ok node loopback");
     }
     std::puts("all ok");
     return 0;

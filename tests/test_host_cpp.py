@@ -23,7 +23,7 @@ def test_host_self_test(binaries, tmp_path):
     assert out.returncode == 0, out.stderr
     assert "all ok" in out.stdout
     for name in ("demo1", "demo2", "yaml errors", "work_units", "channel", "image_builder", "bounded channel",
-                 "render_manager", "cancel"):
+                 "render_manager", "cancel", "cbor", "node messages", "node loopback"):
         assert f"ok {name}" in out.stdout
 
 
@@ -31,8 +31,11 @@ def test_cli_argument_errors(binaries):
     flux = binaries[0]
     r = subprocess.run([flux], capture_output=True, text=True)
     assert r.returncode == 2 and "<scene_file>" in r.stderr
-    r = subprocess.run([flux, os.path.join(SCENES, "demo1.yml"), "-n", "host:2000"], capture_output=True, text=True)
-    assert r.returncode == 2 and "network" in r.stderr
+    # -L -n with nobody listening: "Error connecting to ..." (flux/src/main.rs:60-63); -L alone: no workers
+    r = subprocess.run([flux, os.path.join(SCENES, "demo1.yml"), "-L", "-n", "127.0.0.1:1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Error connecting to 127.0.0.1:1" in r.stderr
+    r = subprocess.run([flux, os.path.join(SCENES, "demo1.yml"), "-L"], capture_output=True, text=True)
+    assert r.returncode == 1 and "No workers specified" in r.stderr
     r = subprocess.run([flux, os.path.join(SCENES, "demo1.yml"), "-g"], capture_output=True, text=True)
     assert r.returncode == 2 and "preview" in r.stderr
     r = subprocess.run([flux, os.path.join(SCENES, "demo1.yml"), "-r", "abc"], capture_output=True, text=True)
@@ -82,3 +85,47 @@ def test_cli_renders_demo1_like_the_oracle(binaries, flux, oracle_mod, demo1, tm
     assert (got != want).mean() < 1e-4
     if rows == 7:  # 600 = 85*7 + 5: last unit is rows 595..599 -> all present; sanity on the partition
         assert present.all()
+
+
+@pytest.mark.gpu
+def test_node_protocol_end_to_end(binaries, tmp_path):
+    """`flux_node` (GPU worker behind the reference's CBOR/TCP node protocol) serving `flux -n host:port -L`:
+    the frame assembled from the node's RowsReady events equals the frame of a direct local render, bit for
+    bit (same seed; colours cross the wire as exact shortest-float CBOR)."""
+    import re
+    import time
+    flux_bin = binaries[0]
+    node_bin = os.path.join(HOST, "flux_node")
+    direct, remote = tmp_path / "direct", tmp_path / "remote"
+    direct.mkdir()
+    remote.mkdir()
+    scene = os.path.join(SCENES, "demo2.yml")
+    common = ["-r", "3", "-d", "5", "-R", "64", "--seed", "5"]
+    r = subprocess.run([flux_bin, scene] + common + ["--gpus", "1", "--outdir", str(direct)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    log = open(tmp_path / "node.log", "w")
+    node = subprocess.Popen([node_bin, "-h", "127.0.0.1", "-p", "0", "-t", "4", "--seed", "5", "--once"],
+                            stdout=log, stderr=subprocess.STDOUT, text=True)
+    try:
+        port = None
+        for _ in range(600):
+            m = re.search(r"Listening on port (\d+)", open(tmp_path / "node.log").read())
+            if m:
+                port = m.group(1)
+                break
+            assert node.poll() is None, open(tmp_path / "node.log").read()
+            time.sleep(0.05)
+        assert port, "flux_node did not come up"
+        r = subprocess.run([flux_bin, scene] + common + ["-L", "-n", f"127.0.0.1:{port}", "--outdir", str(remote)],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "Connecting to worker" in r.stdout and "rendering finished, total time" in r.stdout
+        assert node.wait(timeout=30) == 0
+    finally:
+        if node.poll() is None:
+            node.kill()
+        log.close()
+    a, b = _read_ppm(str(direct / "demo2.ppm")), _read_ppm(str(remote / "demo2.ppm"))
+    assert a.shape == (600, 800, 3) and np.array_equal(a, b)
+    out = open(tmp_path / "node.log").read()
+    assert "Got job" in out and "Got done message" in out
