@@ -263,3 +263,43 @@ def test_gpu_matches_reference_published_render(flux, demo2, math):
     assert np.all(np.abs(d.mean(axis=(0, 1))) < 0.0015), d.mean(axis=(0, 1))  # no colour bias
     assert np.percentile(np.abs(d), 99) < 0.008 and np.abs(d).max() < 0.02
     assert small[:20, 60:].mean() > small[:20, :40].mean()  # glow top-right, far spheres top-left
+
+
+@pytest.mark.parametrize("math", MATH_MODES)
+@pytest.mark.parametrize("variant", [1, 2])
+def test_many_shapes_batches_and_planes(flux, oracle_mod, demo1, math, variant):
+    """More shapes than one 32-wide candidate batch (75 spheres incl. nested/overlapping/coincident ones,
+    4 planes interleaved in YAML order, every material kind): the sphere scan's batching, the plane/sphere
+    tie rule and the hit-record indirection against the oracle's linear scan."""
+    import copy
+    rng = np.random.default_rng(42)
+    sd = copy.deepcopy(small_scene(demo1, 48, 36))
+    shapes = [sd.shapes[0]]  # the inverted environment sphere
+    mats = [lambda: flux.MatteData((rng.uniform(), rng.uniform(), rng.uniform()), (0, 0, 0), rng.uniform(0.3, 1.0)),
+            lambda: flux.EmissiveData((rng.uniform(), rng.uniform(), rng.uniform()), rng.uniform(0.5, 3.0)),
+            lambda: flux.ReflectiveData(rng.uniform(0.3, 0.9), (rng.uniform(), rng.uniform(), rng.uniform())),
+            lambda: flux.GlossyReflectiveData(rng.uniform(0.3, 0.9), (rng.uniform(), rng.uniform(), rng.uniform()),
+                                              float(rng.choice([3.0, 10.0, 101.0, 1000.5])))]
+    for k in range(74):
+        c = (rng.uniform(-4, 9), rng.uniform(0.2, 3.0), rng.uniform(-3, 12))
+        s = flux.SphereData(c, float(rng.uniform(0.2, 1.2)), mats[k % 4](), bool(k % 17 == 5))
+        shapes.append(s)
+        if k % 20 == 7:
+            shapes.append(copy.deepcopy(s))  # coincident twin later in the order: never visible
+            shapes[-1].material = flux.EmissiveData((9.0, 0.0, 9.0), 50.0)
+        if k % 19 == 3:
+            n = (rng.uniform(-0.2, 0.2), 1.0, rng.uniform(-0.2, 0.2))
+            shapes.append(flux.PlaneData((0.0, rng.uniform(-0.5, 0.1), 0.0), n, mats[(k // 19) % 4]()))
+    sd.shapes = shapes
+    assert sum(isinstance(s, flux.SphereData) for s in shapes) > 64 and sum(isinstance(s, flux.PlaneData) for s in shapes) == 4
+    r, o = _pair(flux, oracle_mod, sd, 4, math=math)
+    r.set_kernel(variant)
+    r.enable_stats(True)
+    r.stats(reset=True)
+    got = r.render_frame()
+    o.stats(reset=True)
+    want = o.render_frame(threads=8)
+    st = r.stats()
+    assert {k: st[k] for k in o.stats()} == o.stats()
+    assert max_abs_diff(got, want) < TOL_IMAGE
+    r.close()
