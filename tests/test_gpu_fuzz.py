@@ -1,0 +1,138 @@
+"""Differential fuzzing: random scenes (cameras with and without depth of field, nested / inverted / tiny / huge
+spheres, tilted non-unit planes, every material with awkward parameters, coloured backgrounds) rendered by the
+HIP path in both arithmetics and both kernels against the oracle.  Besides the image tolerance, path
+statistics must match exactly -- any ray/primitive or material decision that differs shows up there."""
+import numpy as np
+import pytest
+
+import copy
+
+from conftest import max_abs_diff, small_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def random_scene(flux, base, rng):
+    sd = copy.deepcopy(base)
+    W, H = int(rng.integers(8, 40)), int(rng.integers(6, 30))
+    sd.output_settings.image_width, sd.output_settings.image_height = W, H
+    sd.output_settings.pixel_size = float(rng.uniform(4.0, 20.0))
+    sd.background = tuple(float(x) for x in rng.uniform(0.0, 1.5, 3)) if rng.uniform() < 0.5 else (0.0, 0.0, 0.0)
+    eye = rng.uniform(-6, 6, 3)
+    eye[1] = abs(eye[1]) + 0.5
+    sd.camera_settings.eye = tuple(float(x) for x in eye)
+    sd.camera_settings.look_at = tuple(float(x) for x in rng.uniform(-1, 1, 3))
+    sd.camera_settings.up = (0.0, 1.0, 0.0) if rng.uniform() < 0.7 else tuple(float(x) for x in rng.normal(size=3))
+    sd.camera_data.lens_radius = float(rng.choice([0.0, 0.05, 0.3]))
+    sd.camera_data.focal_distance = float(rng.uniform(3.0, 12.0))
+    sd.camera_data.zoom_factor = float(rng.uniform(0.5, 2.0))
+
+    def color():
+        return tuple(float(x) for x in rng.uniform(0.0, 1.0, 3))
+
+    def material():
+        k = int(rng.integers(0, 4))
+        if k == 0:
+            return flux.MatteData(color(), color(), float(rng.uniform(0.1, 1.0)))
+        if k == 1:
+            return flux.EmissiveData(color(), float(rng.uniform(0.0, 4.0)))
+        if k == 2:
+            return flux.ReflectiveData(float(rng.uniform(0.1, 1.0)), color())
+        return flux.GlossyReflectiveData(float(rng.uniform(0.1, 1.0)), color(),
+                                         float(rng.choice([0.0, 1.0, 2.5, 10.0, 100.0, 1e4, 1e5])))
+
+    shapes = []
+    if rng.uniform() < 0.7:
+        shapes.append(flux.SphereData((0.0, 0.0, 0.0), float(rng.uniform(20, 200)), flux.EmissiveData(color(), 1.0), True))
+    for _ in range(int(rng.integers(0, 40))):
+        kind = rng.uniform()
+        if kind < 0.8:
+            r = float(rng.choice([rng.uniform(0.05, 0.3), rng.uniform(0.3, 2.0), rng.uniform(2.0, 8.0)]))
+            shapes.append(flux.SphereData(tuple(float(x) for x in rng.uniform(-5, 5, 3)), r, material(), bool(rng.uniform() < 0.15)))
+            if rng.uniform() < 0.1:
+                shapes.append(copy.deepcopy(shapes[-1]))  # coincident twin
+                shapes[-1].material = material()
+        else:
+            n = rng.normal(size=3) * rng.choice([0.3, 1.0, 2.5])  # never normalised by the reference
+            shapes.append(flux.PlaneData(tuple(float(x) for x in rng.uniform(-3, 3, 3)), tuple(float(x) for x in n), material()))
+    sd.shapes = shapes
+    return sd
+
+
+@pytest.mark.parametrize("chunk", range(8))
+def test_random_scenes_against_the_oracle(flux, oracle_mod, demo1, chunk):
+    rng = np.random.default_rng(1000 + chunk)
+    for case in range(40):
+        sd = random_scene(flux, demo1, rng)
+        n = int(rng.choice([1, 2, 3, 8]))
+        D = int(rng.choice([1, 3, 5, 9]))
+        cfg = flux.JobConfiguration(n, D, 50)
+        seed = int(rng.integers(1, 1 << 30))
+        o = oracle_mod.Oracle(sd, cfg, seed=seed)
+        o.stats(reset=True)
+        want = o.render_frame(threads=4)
+        ost = o.stats()
+        finite = np.isfinite(want)
+        with flux.Renderer(sd, cfg, seed=seed) as r:
+            for math in (flux.MATH_FAST, flux.MATH_STRICT):
+                if math == flux.MATH_STRICT and D > 24:
+                    continue
+                r.set_math(math)
+                for variant in (flux.KERNEL_STATIC, flux.KERNEL_REFILL):
+                    r.set_kernel(variant)
+                    r.enable_stats(True)
+                    r.stats(reset=True)
+                    got = r.render_frame()
+                    st = r.stats()
+                    tag = f"chunk {chunk} case {case} math {math} variant {variant} n {n} D {D} shapes {len(sd.shapes)}"
+                    assert {k: st[k] for k in ost} == ost, tag
+                    # NaN pixels (0 * inf in the reference's own arithmetic, e.g. a Phong lobe that underflows)
+                    # must be NaN in STRICT; FAST's closed-form weights may return the finite limit there
+                    if math == flux.MATH_STRICT:
+                        assert np.array_equal(np.isfinite(got), finite), tag
+                    assert max_abs_diff(got[finite], want[finite]) < 1e-4 if finite.any() else True, tag
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_random_meshes_against_the_oracle(flux, oracle_mod, demo1, chunk):
+    """The same with triangle soups added (extension): the BVH state-machine kernel (64 spp), the inline BVH
+    (static kernel, STRICT) and brute force must all take the oracle's decisions."""
+    from flux_amd.scene import MeshData
+    rng = np.random.default_rng(5000 + chunk)
+    for case in range(10):
+        sd = random_scene(flux, demo1, rng)
+        shapes = list(sd.shapes)
+        for _ in range(int(rng.integers(1, 4))):
+            nv = int(rng.integers(3, 60))
+            v = rng.uniform(-4, 4, (nv, 3))
+            v[:, 1] = np.abs(v[:, 1]) * 0.5
+            nt = int(rng.integers(1, 150))
+            t = rng.integers(0, nv, (nt, 3)).astype(np.uint32)  # includes degenerate (repeated-vertex) triangles
+            k = int(rng.integers(0, 3))
+            mat = (flux.MatteData((0.6, 0.5, 0.4), (0, 0, 0), 0.9) if k == 0 else
+                   flux.EmissiveData((0.3, 0.9, 0.4), 2.0) if k == 1 else
+                   flux.GlossyReflectiveData(0.7, (0.9, 0.9, 1.0), 50.0))
+            shapes.append(MeshData(v, t, mat))
+        sd.shapes = shapes
+        n = int(rng.choice([2, 8]))
+        cfg = flux.JobConfiguration(n, int(rng.choice([2, 5])), 50)
+        seed = int(rng.integers(1, 1 << 30))
+        o = oracle_mod.Oracle(sd, cfg, seed=seed)
+        o.stats(reset=True)
+        want = o.render_frame(threads=4)
+        ost = o.stats()
+        finite = np.isfinite(want)
+        with flux.Renderer(sd, cfg, seed=seed) as r:
+            for math in (flux.MATH_FAST, flux.MATH_STRICT):
+                r.set_math(math)
+                for variant in (flux.KERNEL_STATIC, flux.KERNEL_REFILL):
+                    for trav in (flux._lib.TRAVERSE_BVH, flux._lib.TRAVERSE_BRUTE):
+                        r.set_kernel(variant)
+                        r.set_traversal(trav)
+                        r.enable_stats(True)
+                        r.stats(reset=True)
+                        got = r.render_frame()
+                        st = r.stats()
+                        tag = f"chunk {chunk} case {case} math {math} variant {variant} trav {trav} n {n}"
+                        assert {k: st[k] for k in ost} == ost, tag
+                        assert max_abs_diff(got[finite], want[finite]) < 1e-4 if finite.any() else True, tag
