@@ -298,7 +298,14 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
             const double e1[3] = {t.e1x, t.e1y, t.e1z}, e2[3] = {t.e2x, t.e2y, t.e2z};
             double nn[3], nu[3];
             cross3(e1, e2, nn);
-            normalize3(nn, nu);
+            if (nn[0] == 0.0 && nn[1] == 0.0 && nn[2] == 0.0) {
+                // a triangle whose e1 x e2 is exactly zero (repeated or exactly collinear vertices) has no surface:
+                // clearing the edges makes Moeller-Trumbore's det exactly 0, so it is never hit (and never NaN)
+                t.e1x = t.e1y = t.e1z = t.e2x = t.e2y = t.e2z = 0.0;
+                nu[0] = nu[1] = nu[2] = 0.0;
+            } else {
+                normalize3(nn, nu);
+            }
             t.nx = nu[0]; t.ny = nu[1]; t.nz = nu[2];
             t.id = (int32_t)(ns + tris.size());
             t.mat = (int32_t)(ns + m);

@@ -887,7 +887,18 @@ int fxo_ctx_add_mesh(fxo_ctx *c, const double *vertices, size_t num_vertices, co
         t->v0 = v3_new(a[0], a[1], a[2]);
         t->e1 = v3_sub(v3_new(b[0], b[1], b[2]), t->v0);
         t->e2 = v3_sub(v3_new(d[0], d[1], d[2]), t->v0);
-        t->normal = v3_normalize(v3_cross(t->e1, t->e2));
+        {
+            /* extension rule: a triangle whose e1 x e2 is exactly zero (repeated or exactly collinear vertices)
+             * has no surface and is never hit -- its edges are cleared, so det == 0 in fxo tri test */
+            v3 nn = v3_cross(t->e1, t->e2);
+            if (nn.x == 0.0 && nn.y == 0.0 && nn.z == 0.0) {
+                t->e1 = v3_new(0.0, 0.0, 0.0);
+                t->e2 = v3_new(0.0, 0.0, 0.0);
+                t->normal = v3_new(0.0, 0.0, 0.0);
+            } else {
+                t->normal = v3_normalize(nn);
+            }
+        }
         t->mat.kind = mat_kind;
         memcpy(t->mat.p, mat_params, 8 * sizeof(double));
     }
