@@ -65,7 +65,7 @@ struct flux_ctx {
     unsigned char *d_fscene = nullptr;  // FAST path: scan spheres | scan planes | hit records
     double2 *d_pix = nullptr, *d_disc = nullptr;
     double *d_hemi = nullptr;
-    int32_t *d_rowperm = nullptr;
+    int32_t *d_rowperm = nullptr, *d_invperm = nullptr;
     unsigned long long *d_stats = nullptr;
     bool stats_on = false;
     // extension: triangle meshes
@@ -108,6 +108,7 @@ static void free_ctx(flux_ctx *c) {
     (void)hipFree(c->d_disc);
     (void)hipFree(c->d_hemi);
     (void)hipFree(c->d_rowperm);
+    (void)hipFree(c->d_invperm);
     (void)hipFree(c->d_stats);
     (void)hipFree(c->d_tris);
     (void)hipFree(c->d_nodes);
@@ -376,6 +377,7 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     alloc((void **)&c->d_disc, pix_bytes);
     alloc((void **)&c->d_hemi, hemi_bytes);
     alloc((void **)&c->d_rowperm, perm_bytes);
+    alloc((void **)&c->d_invperm, perm_bytes);
     alloc((void **)&c->d_stats, FLUX_NUM_STATS * sizeof(unsigned long long));
     if (!tris.empty()) {
         alloc((void **)&c->d_tris, tris.size() * sizeof(flux::DevTri));
@@ -391,7 +393,7 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     // ---- MasterSampleSets::new on the device (sampling.rs:13-33) --------------
     if (e == hipSuccess)
-        e = flux::generate_tables(seed, c->S, c->D, c->n, c->H, c->d_pix, c->d_disc, c->d_hemi, c->d_rowperm, nullptr);
+        e = flux::generate_tables(seed, c->S, c->D, c->n, c->H, c->d_pix, c->d_disc, c->d_hemi, c->d_rowperm, c->d_invperm, nullptr);
     if (e != hipSuccess) {
         int code = fail(e == hipErrorOutOfMemory ? FLUX_E_NOMEM : FLUX_E_DEVICE, "flux_ctx_create: %s",
                         hipGetErrorString(e));
@@ -404,6 +406,7 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     rp.disc = c->d_disc;
     rp.hemi = c->d_hemi;
     rp.rowperm = c->d_rowperm;
+    rp.invperm = c->d_invperm;
     rp.stats = nullptr;
     rp.tris = c->d_tris;
     rp.nodes = c->d_nodes;

@@ -11,6 +11,11 @@
 #define FLUX_HEMI_AOS4 1
 #endif
 
+// wave -> pixel order: 1 = grouped by sample set with one set per XCD at a time (render_body.inc map_wave), 0 = row-major
+#ifndef FLUX_SET_GROUPED
+#define FLUX_SET_GROUPED 1
+#endif
+
 namespace flux {
 
 constexpr int kHemiDoubles = FLUX_HEMI_AOS4 ? 4 : 3;  // doubles of hemi table per (set, depth, sample)
@@ -106,6 +111,7 @@ struct RenderParams {
     const double2 *disc;  // [S][N] (x,y)                 disc_sets
     const double *hemi;   // hemi_sets: [S][D][N][4] (x,y,z,pad) -- or [S][D][3][N] planes with FLUX_HEMI_AOS4=0
     const int32_t *rowperm;  // [H][S] sample-set index per (row, col)
+    const int32_t *invperm;  // [H][S] its inverse: the column that uses set s in a row
     // work: rows first_row + k*row_stride, k < num_rows
     double *out;          // [num_rows][W][3]
     int32_t first_row, row_stride, num_rows;

@@ -45,6 +45,14 @@ __global__ void row_perm_kernel(uint64_t seed, uint32_t H, uint32_t S, int32_t *
     shuffle_iota(stream_key(seed, kKindRowPerm, row, 0, 0), rowperm + (size_t)row * S, S);
 }
 
+// inverse of each row's permutation: invperm[row][set] = the column whose pixel uses `set`
+__global__ void inv_perm_kernel(uint32_t H, uint32_t S, const int32_t *__restrict__ rowperm, int32_t *__restrict__ invperm) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)H * S) return;
+    const size_t row = t / S;
+    invperm[row * S + (size_t)rowperm[t]] = (int32_t)(t - row * S);
+}
+
 // ---- sample maps ---------------------------------------------------------
 __device__ __forceinline__ double2 mj_point(uint64_t jkey, uint32_t n, uint32_t i, uint32_t k,
                                             uint32_t xi /* px_k[i] */, uint32_t yk /* py_i[k] */) {
@@ -215,7 +223,7 @@ hipError_t generate_sampler_grid(int kind, uint64_t seed, uint32_t n, double *d_
 }
 
 hipError_t generate_tables(uint64_t seed, uint32_t S, uint32_t D, uint32_t n, uint32_t H,
-                           double2 *pix, double2 *disc, double *hemi, int32_t *rowperm,
+                           double2 *pix, double2 *disc, double *hemi, int32_t *rowperm, int32_t *invperm,
                            hipStream_t stream) {
     const size_t N = (size_t)n * n;
     uint16_t *cmj_perms = nullptr, *mj_perms = nullptr;
@@ -233,6 +241,7 @@ hipError_t generate_tables(uint64_t seed, uint32_t S, uint32_t D, uint32_t n, ui
     cmj_perm_kernel<<<blocks_for((size_t)S * 2, 64), 64, 0, stream>>>(seed, kKindDisc, S, n, disc_perms);
     mj_perm_kernel<<<blocks_for((size_t)S * D * 2 * n, bs), bs, 0, stream>>>(seed, S, D, n, mj_perms);
     row_perm_kernel<<<blocks_for(H, 64), 64, 0, stream>>>(seed, H, S, rowperm);
+    inv_perm_kernel<<<blocks_for((size_t)H * S, bs), bs, 0, stream>>>(H, S, rowperm, invperm);
     cmj_fill_kernel<<<blocks_for((size_t)S * N, bs), bs, 0, stream>>>(seed, kKindPixel, S, n, pix_perms, pix);
     cmj_fill_kernel<<<blocks_for((size_t)S * N, bs), bs, 0, stream>>>(seed, kKindDisc, S, n, disc_perms, disc);
     hemi_fill_kernel<<<blocks_for((size_t)S * D * N, bs), bs, 0, stream>>>(seed, S, D, n, mj_perms, hemi);
