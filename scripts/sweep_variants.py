@@ -6,8 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VAR_DIR = os.path.join(ROOT, "flux_amd", "variants")
 VARIANTS = {
-    "grouped": [],
-    "rowmajor": ["-DFLUX_SET_GROUPED=0"],
+    "base": [],
+    "soa": ["-DFLUX_HEMI_AOS4=0"],
+    "w5": ["-DFLUX_WAVES_PER_EU_FAST=5"],
+    "w3": ["-DFLUX_WAVES_PER_EU_FAST=3"],
+    "soaw5": ["-DFLUX_HEMI_AOS4=0", "-DFLUX_WAVES_PER_EU_FAST=5"],
 }
 if "--run" not in sys.argv:
     from flux_amd import build
@@ -42,7 +45,7 @@ for v in (2,):
     err = float(np.abs(img - np.load(ref_path)).max())
     print("  variant %%d: %%8.2f ms  %%8.1f Msamples/s  max|d| vs first = %%.3e" %% (v, best, 800*600*n*n/best/1e3, err), flush=True)
 ''' % (ROOT, ROOT)
-    for lib in sorted(glob.glob(os.path.join(VAR_DIR, "*.so")), key=lambda p: (not p.endswith("_rowmajor.so"), p)):
+    for lib in sorted(glob.glob(os.path.join(VAR_DIR, "*.so")), key=lambda p: (not p.endswith("_base.so"), p)):
         print(os.path.basename(lib), flush=True)
         env = dict(os.environ, FLUX_HIP_LIB=lib)
         subprocess.run([sys.executable, "-c", code], env=env, check=False)
