@@ -50,7 +50,7 @@
 #define FLUX_BVH_REFILL_AT 32     // lanes that must be waiting for shading before the wave leaves traversal
 #endif
 #ifndef FLUX_WAVES_PER_EU_FAST
-#define FLUX_WAVES_PER_EU_FAST 4
+#define FLUX_WAVES_PER_EU_FAST 5
 #endif
 
 

@@ -7,10 +7,8 @@ sys.path.insert(0, ROOT)
 VAR_DIR = os.path.join(ROOT, "flux_amd", "variants")
 VARIANTS = {
     "base": [],
-    "soa": ["-DFLUX_HEMI_AOS4=0"],
     "w5": ["-DFLUX_WAVES_PER_EU_FAST=5"],
-    "w3": ["-DFLUX_WAVES_PER_EU_FAST=3"],
-    "soaw5": ["-DFLUX_HEMI_AOS4=0", "-DFLUX_WAVES_PER_EU_FAST=5"],
+    "w6": ["-DFLUX_WAVES_PER_EU_FAST=6"],
 }
 if "--run" not in sys.argv:
     from flux_amd import build
