@@ -217,7 +217,10 @@ def main():
                          "misses": int(tot_miss),
                          "note": "FP64 path tracer: analytic shapes live in SGPRs; the sample tables (and, for "
                                  "triangle scenes, BVH nodes/triangles) are the only streamed data; bytes are "
-                                 "the algorithmic figure, not inflated.  For triangle scenes the algorithmic "
+                                 "the algorithmic figure, not inflated; with the set-grouped pixel order nearly all of them are "
+                                 "served by the XCD L2s, `traffic` (committed rocprofv3 PMC pass) is what reached the "
+                                 "memory side.  The kernel is FP64-VALU bound (SQ_ACTIVE_INST_VALU 96% of SIMD cycles, "
+                                 "profiles/).  For triangle scenes the algorithmic "
                                  "figure counts every node/triangle record a lane reads (SURVEY 8d), most of "
                                  "which are served by L1/L2/Infinity Cache, so it can exceed the HBM peak; "
                                  "`traffic` is what reached the memory side"},
