@@ -1,0 +1,29 @@
+"""Kernel time of ONE rank's share of the frame for G = 1, 2, 4, 8 (row-interleaved shards), measured on a
+single GPU: what each GPU of an N-GPU run executes, without the collective.  usage: shard_time.py [root]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import flux_amd
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+sd = flux_amd.load_scene("scenes/demo2.yml")
+W, H = sd.output_settings.image_width, sd.output_settings.image_height
+r = flux_amd.Renderer(sd, flux_amd.JobConfiguration(n, 5, 50), seed=1)
+out = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda")
+stream = torch.cuda.current_stream().cuda_stream
+base = None
+for G in (1, 2, 4, 8):
+    times = []
+    for rank in range(G):
+        cnt = (H - rank + G - 1) // G
+        best = 1e30
+        for _ in range(2):
+            r.render_rows_device(rank, G, cnt, out.data_ptr(), stream)
+            torch.cuda.synchronize()
+            best = min(best, r.last_kernel_ms())
+        times.append(best)
+        if G >= 4 and rank >= 1:
+            break  # two ranks are enough to see the spread
+    t = max(times)
+    base = base or t
+    print(f"G={G}: slowest measured rank {t:8.2f} ms  ideal {base / G:8.2f} ms  efficiency {base / G / t * 100:5.1f}%  "
+          f"-> {W * H * n * n / t / 1e3:9.1f} Msamples/s aggregate", flush=True)
