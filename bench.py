@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--kernel", type=int, default=0, help="0 default, 1 static, 2 refill")
     ap.add_argument("--math", default="fast", choices=["fast", "strict"],
                     help="render arithmetic (include/flux_abi.h FLUX_MATH_*); both are FP64 and parity-tested")
+    ap.add_argument("--shard", default="auto", choices=["auto", "rows", "sets"],
+                    help="how the frame is split over GPUs: interleaved rows, or sample sets (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-root", type=int, default=32, help="sample_root of the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -103,7 +105,7 @@ def main():
     import torch.distributed as dist
 
     import flux_amd
-    from flux_amd.dist import FrameSharder, hip_render_fn
+    from flux_amd.dist import FrameSharder, SetSharder, hip_render_fn, hip_render_sets_fn
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the renderer has no CPU fallback)")
@@ -131,8 +133,15 @@ def main():
     t_create = time.perf_counter() - t0
     r.set_kernel(a.kernel)
     r.set_math(flux_amd.MATH_FAST if a.math == "fast" else flux_amd.MATH_STRICT)
-    sh = FrameSharder(H, W, rank, world, dev)
-    fn = hip_render_fn(r)
+    # Shard by sample set (one pixel per row per owned set: balanced, and each rank keeps the full-frame table
+    # locality, flux_amd/dist.py SetSharder) -- the same code path at every N; `--shard rows` forces row tiles.
+    use_sets = a.shard == "sets" or (a.shard == "auto" and n * n >= 64)
+    if use_sets:
+        sh = SetSharder(H, W, rank, world, dev, torch.from_numpy(r.row_perm_table()))
+        fn = hip_render_sets_fn(r)
+    else:
+        sh = FrameSharder(H, W, rank, world, dev)
+        fn = hip_render_fn(r)
 
     def barrier():
         if world > 1:
@@ -181,8 +190,8 @@ def main():
         # pixel 16 B + lens 16 B + 24 B per Matte bounce, plus (triangle scenes) the
         # BVH nodes visited and triangles tested at their laid-out sizes (64 B / 128 B)
         bytes_per_sample = 32.0 + 24.0 * mbar + (tot_nodes * bvh["node_bytes"] + tot_tris * bvh["tri_bytes"]) / tot_samples
-        # the dominant kernel's launch on rank 0 covers samples/world camera paths + its framebuffer rows
-        alg_bytes_launch = (samples / world) * bytes_per_sample + (H / world) * W * 24.0
+        # the dominant kernel's launch on rank 0 covers samples/world camera paths + its share of the framebuffer
+        alg_bytes_launch = (samples / world) * bytes_per_sample + (H * W / world) * 24.0
         achieved = alg_bytes_launch / (kernel_ms_max * 1e-3) / 1e9
         workload = f"{scene_label} {W}x{H} at {n * n} spp (sample_root {n}), depth {a.depth}, seed {a.seed}"
         refill = a.kernel in (0, 2) and n * n >= 64
@@ -203,7 +212,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "kernel": kernel_name.replace("render_", "").replace("_kernel", ""),
                        "math": a.math,
-                       "parallelism": f"row-interleaved image tiles over {world} GPU(s), 1 all_gather",
+                       "parallelism": (f"pixel-set tiles (one pixel per row per owned sample set) over {world} GPU(s), "
+                                       "1 all_gather" if use_sets else
+                                       f"row-interleaved image tiles over {world} GPU(s), 1 all_gather"),
                        "finite": finite},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": load_traffic(workload),

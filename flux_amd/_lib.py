@@ -73,6 +73,7 @@ SYMBOLS = {
     "flux_ctx_destroy": (None, [_P]),
     "flux_render_rows": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]),
     "flux_render_rows_device": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P]),
+    "flux_render_sets_device": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P]),
     "flux_ctx_set_kernel": (C.c_int, [_P, C.c_int]),
     "flux_ctx_set_traversal": (C.c_int, [_P, C.c_int]),
     "flux_ctx_set_math": (C.c_int, [_P, C.c_int]),

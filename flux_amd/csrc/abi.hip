@@ -416,6 +416,10 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     rp.fpln = reinterpret_cast<const flux::DevScanPlane *>(c->d_fscene + fs_sph_bytes);
     rp.frec = reinterpret_cast<const flux::DevHitRec *>(c->d_fscene + fs_sph_bytes + fs_pln_bytes);
     rp.bvh_mag = c->bvh.mag;
+    rp.set_first = 0;
+    rp.set_stride = 1;
+    rp.set_count = (int32_t)c->S;
+    rp.out_by_set = 0;
     rp.n_sph = (int32_t)fsph.size();
     rp.n_pln = (int32_t)fpln.size();
     *out = c;
@@ -507,6 +511,40 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
     if (ctx->math == FLUX_MATH_STRICT && (size_t)ctx->D * 4 * 64 * sizeof(double) > 60 * 1024)
         return fail(FLUX_E_INVALID, "max_trace_depth %u needs %zu B of LDS per block in FLUX_MATH_STRICT (limit 60 KiB); "
                     "use FLUX_MATH_FAST", ctx->D, (size_t)ctx->D * 4 * 64 * sizeof(double));
+    HIP_TRY(hipEventRecord(ctx->ev0, stream));
+    HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
+    HIP_TRY(hipEventRecord(ctx->ev1, stream));
+    ctx->timed = true;
+    return FLUX_OK;
+}
+
+int flux_render_sets_device(flux_ctx *ctx, uint64_t first_set, uint64_t set_stride, uint64_t num_sets, void *d_out_rgb,
+                            void *hip_stream) {
+    if (!ctx) return fail(FLUX_E_INVALID, "null context");
+    if (num_sets == 0) return FLUX_OK;
+    if (!d_out_rgb) return fail(FLUX_E_INVALID, "null output pointer");
+    if (set_stride < 1) return fail(FLUX_E_INVALID, "set_stride must be >= 1");
+    if (first_set >= ctx->S || first_set + (num_sets - 1) * set_stride >= ctx->S)
+        return fail(FLUX_E_INVALID, "sets %llu + k*%llu (k<%llu) exceed the %u sample sets", (unsigned long long)first_set,
+                    (unsigned long long)set_stride, (unsigned long long)num_sets, ctx->S);
+    if (ctx->N < 64 || ctx->variant == FLUX_KERNEL_STATIC || !FLUX_SET_GROUPED)
+        return fail(FLUX_E_INVALID, "set-sharded rendering needs the refill kernel (sample_root^2 >= 64)");
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(FLUX_E_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    hipStream_t stream = (hipStream_t)hip_stream;
+    flux::RenderParams p = ctx->rp;
+    p.out = (double *)d_out_rgb;
+    p.first_row = 0;
+    p.row_stride = 1;
+    p.num_rows = (int32_t)ctx->H;
+    p.set_first = (int32_t)first_set;
+    p.set_stride = (int32_t)set_stride;
+    p.set_count = (int32_t)num_sets;
+    p.out_by_set = 1;
+    p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
+    if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
+    if (ctx->math == FLUX_MATH_STRICT && (size_t)ctx->D * 4 * 64 * sizeof(double) > 60 * 1024)
+        return fail(FLUX_E_INVALID, "max_trace_depth %u too deep for FLUX_MATH_STRICT (LDS recursion stack)", ctx->D);
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
     HIP_TRY(hipEventRecord(ctx->ev1, stream));

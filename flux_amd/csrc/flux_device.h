@@ -128,6 +128,10 @@ struct RenderParams {
     const DevHitRec *frec;  // [n_sph + n_pln]
     int32_t n_sph, n_pln;
     double bvh_mag;  // largest |coordinate| of any mesh vertex (padding scale of the f32 slab test)
+    // work, second axis: sample sets set_first + m*set_stride, m < set_count (default: all S sets).  When
+    // out_by_set != 0 the pixel of (local row k, local set m) is written to out[(k*set_count + m)*3]
+    // instead of out[(k*W + col)*3] (flux_render_sets_device).
+    int32_t set_first, set_stride, set_count, out_by_set;
 };
 
 }  // namespace flux

@@ -61,6 +61,60 @@ class FrameSharder:
         return self.gather()
 
 
+class SetSharder:
+    """Shards the frame by SAMPLE SET instead of by row: rank g renders, in every row, the pixels whose set
+    index s satisfies s % G == g (flux_render_sets_device).  Every row's pixels use a permutation of all sets
+    (trace.rs:64-69), so each rank gets exactly one pixel per row per owned set: a 1/G share with the cost of
+    an average pixel (perfect balance), and -- unlike row shards -- each rank keeps the table locality of the
+    full-frame render (600 rows per set, one set per XCD at a time).  Reassembly is still ONE all_gather, then
+    one indexed read with the row permutation.  `rowperm` is the [H][W] set index of every pixel."""
+
+    def __init__(self, height: int, width: int, rank: int, world: int, device, rowperm: torch.Tensor, group=None):
+        self.height, self.width, self.rank, self.world = height, width, rank, world
+        self.group = group
+        num_sets = width  # workers.rs:50: num_sets = image_width
+        self.count = len(range(rank, num_sets, world))
+        self.cmax = (num_sets + world - 1) // world
+        self.render_buf = torch.zeros((height, self.count, 3), dtype=torch.float64, device=device)
+        padded = self.count != self.cmax
+        self.local = torch.zeros((height, self.cmax, 3), dtype=torch.float64, device=device) if padded else self.render_buf
+        self.gathered = torch.zeros((world, height, self.cmax, 3), dtype=torch.float64, device=device)
+        rp = rowperm.to(device=device, dtype=torch.int64)
+        assert rp.shape == (height, width)
+        self._g = rp % world       # which rank rendered pixel (r, c)
+        self._m = rp // world      # its position among that rank's sets
+        self._r = torch.arange(height, device=device, dtype=torch.int64).unsqueeze(1).expand(height, width)
+
+    def render(self, render_fn: Callable[[int, int, int, torch.Tensor], None]):
+        """render_fn(first_set, set_stride, num_sets, out) fills out[H][num_sets][3] (f64)."""
+        if self.count:
+            render_fn(self.rank, self.world, self.count, self.render_buf)
+
+    def gather(self) -> torch.Tensor:
+        if self.local is not self.render_buf:
+            self.local[:, : self.count] = self.render_buf
+        if self.world == 1:
+            src = self.local.unsqueeze(0)
+        else:
+            dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
+            src = self.gathered
+        return src[self._g, self._r, self._m]  # [H][W][3]
+
+    def step(self, render_fn) -> torch.Tensor:
+        self.render(render_fn)
+        return self.gather()
+
+
+def hip_render_sets_fn(renderer):
+    """SetSharder render_fn backed by the HIP library, launched on torch's current stream."""
+
+    def fn(first, stride, count, out):
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        renderer.render_sets_device(first, stride, count, out.data_ptr(), stream)
+
+    return fn
+
+
 def hip_render_fn(renderer):
     """render_fn backed by the HIP library, launched on torch's current stream."""
 

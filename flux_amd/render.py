@@ -75,6 +75,16 @@ class Renderer:
         _lib.check(_lib.lib.flux_render_rows_device(self._handle(), first_row, row_stride, num_rows,
                                                     C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
+    def render_sets_device(self, first_set: int, set_stride: int, num_sets: int, d_out_ptr: int, stream: int = 0):
+        """Asynchronous device-resident render of the pixels whose sample set is first_set + m*set_stride
+        (see flux_render_sets_device): out[(row*num_sets + m)*3]."""
+        _lib.check(_lib.lib.flux_render_sets_device(self._handle(), first_set, set_stride, num_sets,
+                                                    C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def row_perm_table(self) -> np.ndarray:
+        """[H][S] int32: the sample-set index of every pixel (row, col)."""
+        return np.stack([self.row_perm(r) for r in range(self.height)])
+
     def render_frame(self) -> np.ndarray:
         return self.render_rows(0, self.height - 1)
 

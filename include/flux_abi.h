@@ -161,6 +161,17 @@ int flux_render_rows(flux_ctx *ctx, uint64_t row_start, uint64_t row_end, double
 int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stride,
                             uint64_t num_rows, void *d_out_rgb, void *hip_stream);
 
+/* The same render sharded along the OTHER axis of the work: sample sets instead of rows.  Every pixel of a row
+ * uses a different sample set (trace.rs:64-69: `idx` is a permutation of 0..num_sets, num_sets = image_width,
+ * workers.rs:50), so "the pixels whose set is first_set + m*set_stride, m < num_sets" is exactly one pixel per
+ * row per set -- a 1/G share of the image for set_stride = G, with perfect load balance, and the share whose
+ * sample tables stay cache-resident (DESIGN.md "set-grouped order").  Writes, for every image row r and m <
+ * num_sets, 3 doubles at d_out_rgb[(r*num_sets + m)*3]; the pixel's column is the c with
+ * flux_ctx_copy_row_perm(r)[c] == first_set + m*set_stride.  Asynchronous on `hip_stream` like
+ * flux_render_rows_device.  Needs sample_root^2 >= 64 (refill kernel). */
+int flux_render_sets_device(flux_ctx *ctx, uint64_t first_set, uint64_t set_stride, uint64_t num_sets,
+                            void *d_out_rgb, void *hip_stream);
+
 /* Render-kernel variants (all produce the same image within rounding):
  *   0 = default (currently FLUX_KERNEL_REFILL)
  *   1 = FLUX_KERNEL_STATIC: one lane per sample, lanes idle once their path ends

@@ -7,8 +7,7 @@ sys.path.insert(0, ROOT)
 VAR_DIR = os.path.join(ROOT, "flux_amd", "variants")
 VARIANTS = {
     "base": [],
-    "w5": ["-DFLUX_WAVES_PER_EU_FAST=5"],
-    "w6": ["-DFLUX_WAVES_PER_EU_FAST=6"],
+    "rowmajor": ["-DFLUX_SET_GROUPED=0"],
 }
 if "--run" not in sys.argv:
     from flux_amd import build

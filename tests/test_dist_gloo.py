@@ -71,3 +71,46 @@ def test_rank_rows_partition():
             assert sorted(rows) == list(range(h))
     with pytest.raises(ValueError):
         rank_rows(10, 2, 2)
+
+
+def _set_worker(rank, world, port, width, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    import flux_amd
+    from flux_amd.dist import SetSharder
+    from oracle import oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    height = 12
+    sd = small_scene(flux_amd.load_scene(os.path.join(ROOT, "scenes", "demo2.yml")), width, height)
+    o = oracle.Oracle(sd, flux_amd.JobConfiguration(2, 5, 50), seed=9)
+    full = o.render_frame()
+    rowperm = np.stack([o.row_perm(r) for r in range(height)])
+
+    def render_fn(first, stride, count, out):  # this rank's pixels: one per row per owned set
+        for m in range(count):
+            cols = np.argmax(rowperm == first + m * stride, axis=1)
+            out[:, m] = torch.from_numpy(full[np.arange(height), cols])
+
+    sh = SetSharder(height, width, rank, world, torch.device("cpu"), torch.from_numpy(rowperm))
+    frame = sh.step(render_fn).clone()
+    ok = torch.equal(frame, torch.from_numpy(full))
+    np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.array([int(ok), sh.count]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,width", [(2, 20), (2, 21), (3, 20)])
+def test_set_sharded_frame_equals_single(tmp_path, world, width):
+    """SetSharder: ranks own sample sets (s % G == rank), one all_gather, reassembly through the row permutation;
+    ragged set counts (21 sets over 2 ranks, 20 over 3) are padded."""
+    port = _free_port()
+    mp.spawn(_set_worker, args=(world, port, width, str(tmp_path)), nprocs=world, join=True)
+    counts = []
+    for r in range(world):
+        ok, cnt = np.load(str(tmp_path / f"ok_{r}.npy"))
+        assert ok == 1
+        counts.append(int(cnt))
+    assert sum(counts) == width and max(counts) - min(counts) <= 1

@@ -303,3 +303,35 @@ def test_many_shapes_batches_and_planes(flux, oracle_mod, demo1, math, variant):
     assert {k: st[k] for k in o.stats()} == o.stats()
     assert max_abs_diff(got, want) < TOL_IMAGE
     r.close()
+
+
+@pytest.mark.parametrize("math", MATH_MODES)
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_set_sharded_render_equals_full_frame(flux, demo2, math, world):
+    """flux_render_sets_device: the G per-rank shares (sets s % G == g), rendered one after the other on this one
+    GPU and reassembled by SetSharder's indexing, give the bit-identical frame of the row-based render."""
+    import torch
+    from flux_amd.dist import SetSharder, hip_render_sets_fn
+    sd = small_scene(demo2, 40, 24)
+    dev = torch.device("cuda", 0)
+    with flux.Renderer(sd, flux.JobConfiguration(8, 5, 50), seed=3) as r:
+        r.set_math(_mode(flux, math))
+        full = torch.from_numpy(r.render_frame())
+        rowperm = torch.from_numpy(r.row_perm_table())
+        fn = hip_render_sets_fn(r)
+        shards = []
+        for rank in range(world):
+            sh = SetSharder(24, 40, rank, world, dev, rowperm)
+            sh.render(fn)
+            torch.cuda.synchronize()
+            sh.local[:, : sh.count] = sh.render_buf
+            shards.append(sh)
+        gathered = torch.stack([s.local for s in shards])  # what all_gather_into_tensor produces
+        s0 = shards[0]
+        frame = gathered[s0._g, s0._r, s0._m].cpu()
+        assert torch.equal(frame, full)
+        with pytest.raises(flux.FluxError):
+            r.render_sets_device(0, 1, 41, s0.render_buf.data_ptr())   # more sets than exist
+        r.set_kernel(flux.KERNEL_STATIC)
+        with pytest.raises(flux.FluxError):
+            r.render_sets_device(0, 1, 40, s0.render_buf.data_ptr())   # needs the refill kernel
