@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT)
 VAR_DIR = os.path.join(ROOT, "flux_amd", "variants")
 VARIANTS = {
     "base": [],
-    "rowmajor": ["-DFLUX_SET_GROUPED=0"],
+    "w6": ["-DFLUX_WAVES_PER_EU_FAST=6"],
+    "w4": ["-DFLUX_WAVES_PER_EU_FAST=4"],
 }
 if "--run" not in sys.argv:
     from flux_amd import build
