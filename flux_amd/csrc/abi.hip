@@ -508,9 +508,14 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
     p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
     // STRICT keeps the (f,s) recursion stack in LDS: 4 doubles per level per lane, 64-thread blocks
-    if (ctx->math == FLUX_MATH_STRICT && (size_t)ctx->D * 4 * 64 * sizeof(double) > 60 * 1024)
-        return fail(FLUX_E_INVALID, "max_trace_depth %u needs %zu B of LDS per block in FLUX_MATH_STRICT (limit 60 KiB); "
-                    "use FLUX_MATH_FAST", ctx->D, (size_t)ctx->D * 4 * 64 * sizeof(double));
+    {
+        // STRICT keeps the (f,s) recursion stack in LDS: 4 doubles per level per lane; refill blocks hold up to 4 waves
+        size_t strict_threads = 64;  // 64 * K, K as in launch_render
+        while (strict_threads * 2 <= 64 * FLUX_MAX_WAVES_PER_PIXEL && strict_threads * 2 * 16 <= ctx->N) strict_threads *= 2;
+        if (ctx->math == FLUX_MATH_STRICT && (size_t)ctx->D * 4 * strict_threads * sizeof(double) > 60 * 1024)
+            return fail(FLUX_E_INVALID, "max_trace_depth %u needs %zu B of LDS per block in FLUX_MATH_STRICT (limit 60 KiB); "
+                        "use FLUX_MATH_FAST", ctx->D, (size_t)ctx->D * 4 * strict_threads * sizeof(double));
+    }
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
     HIP_TRY(hipEventRecord(ctx->ev1, stream));
@@ -543,7 +548,7 @@ int flux_render_sets_device(flux_ctx *ctx, uint64_t first_set, uint64_t set_stri
     p.out_by_set = 1;
     p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
-    if (ctx->math == FLUX_MATH_STRICT && (size_t)ctx->D * 4 * 64 * sizeof(double) > 60 * 1024)
+    if (ctx->math == FLUX_MATH_STRICT && (size_t)ctx->D * 4 * 64 * FLUX_MAX_WAVES_PER_PIXEL * sizeof(double) > 60 * 1024)
         return fail(FLUX_E_INVALID, "max_trace_depth %u too deep for FLUX_MATH_STRICT (LDS recursion stack)", ctx->D);
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));

@@ -16,6 +16,11 @@
 #define FLUX_SET_GROUPED 1
 #endif
 
+// refill kernel: most waves that share one pixel's samples (launch_render picks K <= this, a power of two)
+#ifndef FLUX_MAX_WAVES_PER_PIXEL
+#define FLUX_MAX_WAVES_PER_PIXEL 4
+#endif
+
 namespace flux {
 
 constexpr int kHemiDoubles = FLUX_HEMI_AOS4 ? 4 : 3;  // doubles of hemi table per (set, depth, sample)

@@ -6,9 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VAR_DIR = os.path.join(ROOT, "flux_amd", "variants")
 VARIANTS = {
-    "base": [],
-    "w6": ["-DFLUX_WAVES_PER_EU_FAST=6"],
-    "w4": ["-DFLUX_WAVES_PER_EU_FAST=4"],
+    "k4": [],
+    "k8": ["-DFLUX_MAX_WAVES_PER_PIXEL=8"],
+    "k2": ["-DFLUX_MAX_WAVES_PER_PIXEL=2"],
 }
 if "--run" not in sys.argv:
     from flux_amd import build
