@@ -76,19 +76,19 @@ def cpu_baseline(sd, depth, seed, cpu_root):
                       f"(row-parallel); table build {t_tables:.2f} s excluded, as for the GPU value"}
 
 
-def load_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*pmc*.json), if one
-    matches this workload; else None."""
+def load_profile(workload):
+    """The newest committed rocprofv3 PMC summary (profiles/*pmc*.json, scripts/summarize_profile.py) of this
+    workload: (HBM bytes per launch, fraction of SIMD cycles issuing VALU instructions, file name) or Nones."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
             if d.get("workload") == workload:
-                return d.get("hbm_bytes_per_launch")
+                return d.get("hbm_bytes_per_launch"), d.get("valu_busy_frac"), os.path.basename(path)
         except Exception:
             continue
-    return None
+    return None, None, None
 
 
 def main():
@@ -197,6 +197,7 @@ def main():
         refill = a.kernel in (0, 2) and n * n >= 64
         kernel_name = ("render_bvh_kernel" if refill and a.math == "fast" and bvh["triangles"] > 0 else
                        "render_refill_kernel" if refill else "render_static_kernel")
+        traffic, valu_busy, profile_name = load_profile(workload)
         out = {
             "metric": "Msamples/sec on demo2.yml (fixed spp)",
             "value": round(samples * a.steps / elapsed_max / 1e6, 3),
@@ -217,7 +218,8 @@ def main():
                                        f"row-interleaved image tiles over {world} GPU(s), 1 all_gather"),
                        "finite": finite},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": load_traffic(workload),
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "valu_busy_frac": None if valu_busy is None else round(valu_busy, 4), "profile": profile_name,
                          "kernel": kernel_name,
                          "kernel_ms": round(kernel_ms_max, 3), "bytes_per_sample": round(bytes_per_sample, 3),
                          "matte_bounces_per_sample": round(mbar, 5),

@@ -75,5 +75,12 @@ if main and "FETCH_SIZE" in main and "WRITE_SIZE" in main:
         scale = sum(ratios) / len(ratios)
     out["fetch_scale"] = scale
     out["hbm_bytes_per_launch"] = (main["FETCH_SIZE"] * scale + main["WRITE_SIZE"]) * 1024.0
+if main and "SQ_ACTIVE_INST_VALU" in main and "SQ_BUSY_CYCLES" in main and main["SQ_BUSY_CYCLES"]:
+    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader
+    # engines (MI355X_MICROARCH.md): busy fraction of the 1024 SIMDs' cycles spent issuing VALU instructions
+    cycles = main["SQ_BUSY_CYCLES"] / 32.0
+    out["valu_busy_frac"] = main["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * 1024.0)
+    if "SQ_INSTS_VALU" in main and "SQ_WAVES" in main:
+        out["valu_insts_per_launch"] = main["SQ_INSTS_VALU"]
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "bench_lines"}, indent=1)[:3000])
