@@ -186,7 +186,9 @@ int flux_ctx_set_kernel(flux_ctx *ctx, int variant);
  * north-star tolerance (1e-4 per channel):
  *   FLUX_MATH_FAST (default): the reference's estimator evaluated for the machine -- FMA contraction,
  *       division/sqrt/pow/sincos from flux_math.h (<= ~2 ulp), no BoundingBox::hit pre-test (implied by
- *       the sphere quadratic), path throughput multiplied front to back;
+ *       the sphere quadratic), path throughput multiplied front to back, bounce weights in closed form (where the
+ *       reference's long form under/overflows -- only possible with non-unit plane normals -- it yields NaN and
+ *       FAST the analytic value);
  *   FLUX_MATH_STRICT: the reference's operation order, no contraction, IEEE division/sqrt, OCML
  *       pow/sincos, BoundingBox::hit before every sphere, (f,s) stack folded deepest bounce first. */
 #define FLUX_MATH_FAST 0
