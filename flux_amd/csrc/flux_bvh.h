@@ -33,7 +33,10 @@ static_assert(sizeof(DevNode) == 64, "DevNode layout");
 
 constexpr int kBvhSahDepth = 32;    // below this depth the builder uses SAH, deeper: median splits
 constexpr int kBvhMaxDepth = 64;    // hard limit; the per-lane LDS stack is sized max_depth entries
-constexpr int kBvhLeafSize = 4;
+#ifndef FLUX_BVH_LEAF
+#define FLUX_BVH_LEAF 2
+#endif
+constexpr int kBvhLeafSize = FLUX_BVH_LEAF;  // <= 7: leaf references carry the count in 3 bits
 
 struct BvhInfo {
     uint64_t nodes = 0, tris = 0, max_depth = 0, max_leaf = 0, build_us = 0;
