@@ -44,7 +44,7 @@
 #define FLUX_WAVES_PER_EU 3
 #endif
 #ifndef FLUX_WPE_BVH
-#define FLUX_WPE_BVH 4            // waves/SIMD of the BVH traversal kernel
+#define FLUX_WPE_BVH 5            // waves/SIMD of the BVH traversal kernel
 #endif
 #ifndef FLUX_BVH_REFILL_AT
 #define FLUX_BVH_REFILL_AT 32     // lanes that must be waiting for shading before the wave leaves traversal
