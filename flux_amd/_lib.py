@@ -77,6 +77,8 @@ SYMBOLS = {
     "flux_ctx_set_kernel": (C.c_int, [_P, C.c_int]),
     "flux_ctx_set_traversal": (C.c_int, [_P, C.c_int]),
     "flux_ctx_set_math": (C.c_int, [_P, C.c_int]),
+    "flux_debug_shade": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_double), C.c_uint64, C.c_uint64, C.c_uint64,
+                                   C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "flux_sampler_grid": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double)]),
     "flux_debug_fastmath": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),

@@ -441,6 +441,40 @@ int flux_ctx_set_math(flux_ctx *ctx, int mode) {
     return FLUX_OK;
 }
 
+int flux_debug_shade(flux_ctx *ctx, uint64_t n, const double *rays, uint64_t depth, uint64_t set_index,
+                     uint64_t sample_index, double *out_rgb, int32_t *out_hit, double *out_t) {
+    if (!ctx || !rays || !out_rgb) return fail(FLUX_E_INVALID, "null argument");
+    if (n == 0) return FLUX_OK;
+    if (n > (1u << 24)) return fail(FLUX_E_INVALID, "too many rays");
+    if (depth < 1 || set_index >= ctx->S || sample_index >= ctx->N)
+        return fail(FLUX_E_INVALID, "depth >= 1, set_index < %u and sample_index < %u required", ctx->S, ctx->N);
+    if (ctx->math == FLUX_MATH_STRICT && (size_t)ctx->D * 4 * 64 * sizeof(double) > 60 * 1024)
+        return fail(FLUX_E_INVALID, "max_trace_depth %u too deep for FLUX_MATH_STRICT (LDS recursion stack)", ctx->D);
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return fail(FLUX_E_DEVICE, "hipSetDevice(%d) failed", ctx->device);
+    double *d_rays = nullptr, *d_rgb = nullptr, *d_t = nullptr;
+    int *d_hit = nullptr;
+    hipError_t e = hipMalloc((void **)&d_rays, (size_t)n * 6 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_rgb, (size_t)n * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_t, (size_t)n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_hit, (size_t)n * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice);
+    flux::RenderParams p = ctx->rp;
+    if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
+    if (e == hipSuccess)
+        e = flux::launch_shade_rays(p, ctx->math, d_rays, (int)n, (int)depth, (uint32_t)set_index, (uint32_t)sample_index,
+                                    d_rgb, d_hit, d_t, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_rgb, d_rgb, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_hit) e = hipMemcpy(out_hit, d_hit, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_t) e = hipMemcpy(out_t, d_t, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_rays);
+    (void)hipFree(d_rgb);
+    (void)hipFree(d_t);
+    (void)hipFree(d_hit);
+    if (e != hipSuccess) return fail(FLUX_E_DEVICE, "debug shade: %s", hipGetErrorString(e));
+    return FLUX_OK;
+}
+
 int flux_sampler_grid(int device, int kind, uint64_t sample_root, uint64_t seed, double *out_xy, double *out_hemi) {
     if (!out_xy) return fail(FLUX_E_INVALID, "null output");
     if (kind < FLUX_SAMPLER_REGULAR || kind > FLUX_SAMPLER_CORRELATED_MULTI_JITTERED)

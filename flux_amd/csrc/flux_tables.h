@@ -21,6 +21,10 @@ hipError_t hemi_to_aos(size_t SD, size_t N, const double *in, double *out, hipSt
 // math: FLUX_MATH_FAST / FLUX_MATH_STRICT (render_body.inc).
 hipError_t launch_render(const RenderParams &p, int variant, int math, hipStream_t stream);
 
+// Scene::shade for caller-supplied rays (device pointers; rays = n x (origin, direction)).
+hipError_t launch_shade_rays(const RenderParams &p, int math, const double *d_rays, int n, int depth, uint32_t set,
+                             uint32_t index, double *d_rgb, int *d_hit, double *d_t, hipStream_t stream);
+
 // flux_math.h under test: out[i] = fn(a[i], b[i]) on the device (b may be null).
 hipError_t launch_fastmath_probe(int fn, const double *a, const double *b, double *out, size_t n,
                                  hipStream_t stream);

@@ -86,6 +86,12 @@ hipError_t launch_render(const RenderParams &p, int variant, int math, hipStream
     return fast::launch_render_impl(p, variant, stream);
 }
 
+hipError_t launch_shade_rays(const RenderParams &p, int math, const double *d_rays, int n, int depth, uint32_t set,
+                             uint32_t index, double *d_rgb, int *d_hit, double *d_t, hipStream_t stream) {
+    if (math == FLUX_MATH_STRICT) return strict::launch_shade_rays_impl(p, d_rays, n, depth, set, index, d_rgb, d_hit, d_t, stream);
+    return fast::launch_shade_rays_impl(p, d_rays, n, depth, set, index, d_rgb, d_hit, d_t, stream);
+}
+
 // ---- flux_math.h under test: out[i] = fn(a[i], b[i]) computed on the device ----------------------
 __global__ void fastmath_probe_kernel(int fn, const double *a, const double *b, double *out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -81,6 +81,22 @@ class Renderer:
         _lib.check(_lib.lib.flux_render_sets_device(self._handle(), first_set, set_stride, num_sets,
                                                     C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
+    def debug_shade(self, origins, directions, depth: int = 1, set_index: int = 0, sample_index: int = 0):
+        """Scene::shade on the device for the given rays (flux_debug_shade): (rgb [n,3], first-hit index [n], t [n])."""
+        o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+        assert o.shape == d.shape
+        rays = np.ascontiguousarray(np.concatenate([o, d], axis=1))
+        n = rays.shape[0]
+        rgb = np.empty((n, 3), dtype=np.float64)
+        hit = np.empty(n, dtype=np.int32)
+        t = np.empty(n, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        _lib.check(_lib.lib.flux_debug_shade(self._handle(), n, rays.ctypes.data_as(dp), depth, set_index, sample_index,
+                                             rgb.ctypes.data_as(dp), hit.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             t.ctypes.data_as(dp)))
+        return rgb, hit, t
+
     def row_perm_table(self) -> np.ndarray:
         """[H][S] int32: the sample-set index of every pixel (row, col)."""
         return np.stack([self.row_perm(r) for r in range(self.height)])

@@ -243,6 +243,14 @@ uint64_t flux_ctx_device_bytes(flux_ctx *ctx);
 #define FLUX_SAMPLER_CORRELATED_MULTI_JITTERED 3
 int flux_sampler_grid(int device, int kind, uint64_t sample_root, uint64_t seed, double *out_xy, double *out_hemi);
 
+/* Test hook: Scene::shade (scene.rs:162-172) on the device for `n` caller-supplied rays (rays = n x {origin[3],
+ * direction[3]}, host memory), each traced from `depth` (1 = a primary ray) with sample (set_index, sample_index) of
+ * the context's tables and the context's arithmetic (flux_ctx_set_math).  out_rgb: n x 3 (un-clamped radiance, what
+ * Scene::shade returns); out_hit: first hit per ray as the shape's YAML index, num_shapes + triangle index, or -1
+ * (Scene::hit, scene.rs:156-160); out_t: its distance.  out_hit / out_t may be NULL. */
+int flux_debug_shade(flux_ctx *ctx, uint64_t n, const double *rays, uint64_t depth, uint64_t set_index,
+                     uint64_t sample_index, double *out_rgb, int32_t *out_hit, double *out_t);
+
 /* Test hook for csrc/flux_math.h: out[i] = fn(a[i], b[i]) evaluated ON THE DEVICE (host pointers in,
  * host pointer out; b may be NULL for unary functions).  fn: 0 frsqrt, 1 fsqrt, 2 fdiv, 3 flog2,
  * 4 fexp2, 5 fpow_pos, 6 sin(2 pi a), 7 cos(2 pi a), 8 raw v_rsq_f64, 9 raw v_rcp_f64. */
