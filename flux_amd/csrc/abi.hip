@@ -159,6 +159,12 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     if (cfg->max_trace_depth < 1 || cfg->max_trace_depth > 256)
         return fail(FLUX_E_INVALID, "max_trace_depth must be in [1,256], got %llu",
                     (unsigned long long)cfg->max_trace_depth);
+    // the render kernels address a pixel's Lambertian samples with a 32-bit byte offset from the set's base:
+    // max_trace_depth * sample_root^2 * 32 B must stay below 4 GiB (the table of even ONE narrow image row would
+    // otherwise be enormous: this only excludes e.g. sample_root 4096 with depth >= 8)
+    if ((uint64_t)cfg->max_trace_depth * cfg->sample_root * cfg->sample_root * 32ull >= (1ull << 32))
+        return fail(FLUX_E_INVALID, "max_trace_depth * sample_root^2 = %llu is too large (limit 2^27 = 134217728)",
+                    (unsigned long long)(cfg->max_trace_depth * cfg->sample_root * cfg->sample_root));
     if (scene->image_width < 1 || scene->image_height < 1 || scene->image_width > 65535 ||
         scene->image_height > (1u << 20))
         return fail(FLUX_E_INVALID, "image size %llux%llu out of range",

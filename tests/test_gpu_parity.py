@@ -178,6 +178,8 @@ def test_abi_errors(flux, demo1):
         flux.Renderer(sd, flux.JobConfiguration(2, 0, 50))
     with pytest.raises(flux.FluxError):
         flux.Renderer(sd, flux.JobConfiguration(2, 5, 50), device=99)
+    with pytest.raises(flux.FluxError):
+        flux.Renderer(sd, flux.JobConfiguration(4096, 8, 50))   # depth * spp beyond the 32-bit table offsets
     r = flux.Renderer(sd, flux.JobConfiguration(2, 5, 50))
     with pytest.raises(flux.FluxError):
         r.render_rows(0, 8)      # row_end == H is out of range
