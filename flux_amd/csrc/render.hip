@@ -8,26 +8,24 @@
 // Color::max_to_one (color.rs:35-44).
 //
 // Mapping to the machine (not a translation of the reference's recursion):
-//  * one lane = one camera path; a wave owns one pixel (n*n >= 64) and walks its
-//    samples 64 at a time, so pixel/lens/hemisphere table reads are contiguous
-//    across the wave (16 B or 8 B per lane);
-//  * the scene (<= a few dozen shapes) is read with a wave-uniform index ->
-//    scalar loads, operands sit in SGPRs; only the nearest hit's shape and
-//    material are gathered per lane;
-//  * the reference's recursion  L = (f1 (*) ((f2 (*) (...)) * s2)) * s1  is run
-//    iteratively: each bounce pushes (f, s = n.wi/pdf) on a per-lane stack in
-//    LDS ([level][4][lane], conflict-free) and the stack is folded from the
-//    deepest bounce outward when the path ends, reproducing the reference's
-//    multiplication order;
-//  * REFILL variant: a lane whose path ended immediately takes the pixel's next
-//    unstarted sample (ballot + mbcnt prefix), so lanes stay busy although path
-//    lengths differ (1..D segments);
-//  * per-lane partial sums are combined in lane order by the pixel's leader
-//    lane (fixed order => bit-reproducible run to run), then * 1/n^2 and
-//    max_to_one, and the 3 doubles are written once.  No atomics.
+//  * one lane = one camera path; one BLOCK owns one pixel: its 1..4 waves take contiguous slices of the
+//    pixel's samples and each walks its slice 64 at a time, so pixel/lens table reads are contiguous
+//    across the wave (16 B per lane);
+//  * blocks are ordered by sample set and dealt to the 8 XCDs so that the tables of the set being worked on
+//    stay in that XCD's L2 (render_body.inc map_wave);
+//  * the scene (<= a few dozen shapes) is read with a wave-uniform index -> scalar loads, operands sit in
+//    SGPRs; only the nearest hit's record is gathered per lane;
+//  * the reference's recursion  L = (f1 (*) ((f2 (*) (...)) * s2)) * s1  is run iteratively -- STRICT pushes
+//    (f, s = n.wi/pdf) on a per-lane LDS stack and folds it from the deepest bounce outward (the reference's
+//    multiplication order), FAST multiplies a register throughput;
+//  * REFILL variant: a lane whose path ended immediately takes the slice's next unstarted sample (ballot +
+//    mbcnt prefix), so lanes stay busy although path lengths differ (1..D segments);
+//  * per-lane partial sums are combined in lane order, wave totals in wave order (a fixed tree => the image is
+//    bit-reproducible run to run and independent of how the frame is split), then * 1/n^2, max_to_one, and the
+//    3 doubles are written once.  No atomics.
 //
-// Compiled with -ffp-contract=off: the operation order below is the
-// reference's, and a*b+c is not fused (rustc never contracts).
+// The loop body (render_body.inc) is compiled twice: STRICT under `#pragma clang fp contract(off)` with the
+// reference's operation order, FAST under contract(fast) with flux_math.h (see render_body.inc's header).
 #include "flux_device.h"
 #include "flux_tables.h"
 #include "flux_math.h"
