@@ -95,14 +95,35 @@ def load_profile(workload):
     return None, None, None
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` from a bare shell: start N fresh ranks under torch.distributed.run and return
+    their exit code.  Runs BEFORE torch / flux_amd are imported, so this process never touches the GPU (a process
+    that has initialised HIP must not exec or fork GPU work); the children are new interpreters.  The reference's
+    equivalent fan-out is in-process (fluxcore/src/manager.rs:156-162: one clone of the job per worker)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit(f"--gpus {a.gpus} needs a torch.distributed.run launch with {a.gpus} ranks")
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but launched with WORLD_SIZE {world}; using {world}", file=sys.stderr)
         a.gpus = world
 
     import torch

@@ -133,8 +133,15 @@ __global__ void hemi_fill_kernel(uint64_t seed, uint32_t S, uint32_t D, uint32_t
     uint32_t d = (uint32_t)(sd % D), s = (uint32_t)(sd / D);
     uint32_t i = p / n, k = p % n;
     const uint16_t *pb = perms + sd * (2ull * n) * n;
+#ifdef FLUX_EXP_HEMI_CMJ
+    // EXPERIMENT (scripts/ref16_variance.py, never the product build): ONE y- and ONE x-permutation per grid, i.e. the
+    // correlated variant's structure (lib.rs:75-90) for the hemisphere stream, to test what it does to the variance
+    uint32_t yk = pb[k];
+    uint32_t xi = pb[(size_t)n * n + i];
+#else
     uint32_t yk = pb[(size_t)i * n + k];        // y-shuffle of row i, element k
     uint32_t xi = pb[((size_t)n + k) * n + i];  // x-shuffle of column k, element i
+#endif
     double2 q = mj_point(stream_key(seed, kKindHemi, s, d, kSubJitter), n, i, k, xi, yk);
     double pu, pv, pw;
     unit_hemi_e0(q, pu, pv, pw);
