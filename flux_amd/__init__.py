@@ -5,7 +5,7 @@ kernels behind the C ABI of include/flux_abi.h).  Importing it without the
 built library raises ImportError: there is no CPU fallback.
 """
 from . import _lib
-from ._lib import FluxError, KERNEL_DEFAULT, KERNEL_REFILL, KERNEL_STATIC, MATH_FAST, MATH_STRICT
+from ._lib import FluxError, KERNEL_DEFAULT, KERNEL_REFILL, KERNEL_SPLIT, KERNEL_STATIC, MATH_FAST, MATH_STRICT
 from .render import Renderer, debug_fastmath, sampler_grid, work_units, write_ppm
 from .scene import (CameraData, CameraSettings, EmissiveData, GlossyReflectiveData, JobConfiguration, MatteData,
                     OutputSettings, PlaneData, ReflectiveData, SceneData, SceneError, SphereData, WorkUnit,
@@ -15,5 +15,5 @@ __all__ = [
     "FluxError", "Renderer", "work_units", "write_ppm", "load_scene", "scene_from_dict", "SceneData", "SceneError",
     "CameraSettings", "CameraData", "OutputSettings", "SphereData", "PlaneData", "MatteData", "EmissiveData",
     "ReflectiveData", "GlossyReflectiveData", "JobConfiguration", "WorkUnit", "WorkUnitResult", "KERNEL_DEFAULT",
-    "KERNEL_STATIC", "KERNEL_REFILL", "MATH_FAST", "MATH_STRICT", "debug_fastmath", "sampler_grid",
+    "KERNEL_STATIC", "KERNEL_REFILL", "KERNEL_SPLIT", "MATH_FAST", "MATH_STRICT", "debug_fastmath", "sampler_grid",
 ]

@@ -15,7 +15,7 @@ FLUX_OK = 0
 E_INVALID, E_DEVICE, E_NOMEM, E_IO = -1, -2, -3, -4
 SHAPE_SPHERE, SHAPE_PLANE = 0, 1
 MAT_MATTE, MAT_EMISSIVE, MAT_REFLECTIVE, MAT_GLOSSY = 0, 1, 2, 3
-KERNEL_DEFAULT, KERNEL_STATIC, KERNEL_REFILL = 0, 1, 2
+KERNEL_DEFAULT, KERNEL_STATIC, KERNEL_REFILL, KERNEL_SPLIT = 0, 1, 2, 3
 MATH_FAST, MATH_STRICT = 0, 1
 SAMPLER_REGULAR, SAMPLER_JITTERED, SAMPLER_MULTI_JITTERED, SAMPLER_CORRELATED_MULTI_JITTERED = 0, 1, 2, 3
 TABLE_PIXEL, TABLE_DISC, TABLE_HEMI = 0, 1, 2
@@ -97,7 +97,22 @@ SYMBOLS = {
 }
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process.  The PyTorch wheel ships its own libamdhip64.so (SONAME libamdhip64.so.7, the
+    name libflux_hip.so links against).  Loaded first, it satisfies this library's dependency and both share one
+    runtime -- streams and device buffers handed over by flux_amd/dist.py are then valid on both sides.  Loaded
+    second, it comes in BESIDE /opt/rocm's copy and `torch.cuda` can no longer initialise the device.  So when torch is
+    installed it is imported before the library is loaded (FLUX_NO_TORCH=1 skips this for torch-free embedders)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("FLUX_NO_TORCH"):
+        return
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def _load():
+    _one_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -m flux_amd.build` "

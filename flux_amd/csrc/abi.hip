@@ -65,6 +65,7 @@ struct flux_ctx {
     unsigned char *d_fscene = nullptr;  // FAST path: scan spheres | scan planes | hit records
     double2 *d_pix = nullptr, *d_disc = nullptr;
     double *d_hemi = nullptr;
+    double *d_gloss = nullptr;  // FAST glossy-lobe factors of pixel_sets
     int32_t *d_rowperm = nullptr, *d_invperm = nullptr;
     unsigned long long *d_stats = nullptr;
     bool stats_on = false;
@@ -107,6 +108,7 @@ static void free_ctx(flux_ctx *c) {
     (void)hipFree(c->d_pix);
     (void)hipFree(c->d_disc);
     (void)hipFree(c->d_hemi);
+    (void)hipFree(c->d_gloss);
     (void)hipFree(c->d_rowperm);
     (void)hipFree(c->d_invperm);
     (void)hipFree(c->d_stats);
@@ -382,6 +384,7 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     alloc((void **)&c->d_pix, pix_bytes);
     alloc((void **)&c->d_disc, pix_bytes);
     alloc((void **)&c->d_hemi, hemi_bytes);
+    if (FLUX_GLOSS_TABLE) alloc((void **)&c->d_gloss, pix_bytes * 2);
     alloc((void **)&c->d_rowperm, perm_bytes);
     alloc((void **)&c->d_invperm, perm_bytes);
     alloc((void **)&c->d_stats, FLUX_NUM_STATS * sizeof(unsigned long long));
@@ -400,6 +403,10 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     // ---- MasterSampleSets::new on the device (sampling.rs:13-33) --------------
     if (e == hipSuccess)
         e = flux::generate_tables(seed, c->S, c->D, c->n, c->H, c->d_pix, c->d_disc, c->d_hemi, c->d_rowperm, c->d_invperm, nullptr);
+    if (e == hipSuccess && FLUX_GLOSS_TABLE) {
+        e = flux::generate_gloss_table(c->d_pix, (size_t)c->S * c->N, c->d_gloss, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    }
     if (e != hipSuccess) {
         int code = fail(e == hipErrorOutOfMemory ? FLUX_E_NOMEM : FLUX_E_DEVICE, "flux_ctx_create: %s",
                         hipGetErrorString(e));
@@ -411,6 +418,7 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     rp.pix = c->d_pix;
     rp.disc = c->d_disc;
     rp.hemi = c->d_hemi;
+    rp.gloss = c->d_gloss;
     rp.rowperm = c->d_rowperm;
     rp.invperm = c->d_invperm;
     rp.stats = nullptr;
@@ -434,7 +442,7 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
 
 int flux_ctx_set_kernel(flux_ctx *ctx, int variant) {
     if (!ctx) return fail(FLUX_E_INVALID, "null context");
-    if (variant < FLUX_KERNEL_DEFAULT || variant > FLUX_KERNEL_REFILL)
+    if (variant < FLUX_KERNEL_DEFAULT || variant > FLUX_KERNEL_SPLIT)
         return fail(FLUX_E_INVALID, "unknown kernel variant %d", variant);
     ctx->variant = variant;
     return FLUX_OK;

@@ -16,6 +16,21 @@
 #define FLUX_SET_GROUPED 1
 #endif
 
+// FAST glossy lobe: 1 = the sample-only factors of to_unit_hemi (samplers/src/lib.rs:133-142) -- cos/sin of 2 pi x and
+// log2(1 - y) of the PIXEL sample, which GlossySpecular::sample_f (brdf.rs:64) re-maps at every bounce -- are computed
+// once per sample at table-build time (tables: `gloss` [S][N][4]); the render loop is left with one exp2 and a sqrt.
+#ifndef FLUX_GLOSS_TABLE
+#define FLUX_GLOSS_TABLE 1
+#endif
+
+// FAST sphere scan: 1 = exact tests of the spheres the ray origin is inside of run last and are skipped when the best hit
+// so far lies strictly inside them (render_body.inc scan_shapes_fast).  Measured on demo2 at 16384 spp: 330 -> 361 ms in
+// the per-lane candidate loop (the second pass costs more loop overhead than the skipped square roots save), so it is
+// off there; the wave-uniform primary scan (scan_shapes_primary) always does it.
+#ifndef FLUX_DEFER_INSIDE
+#define FLUX_DEFER_INSIDE 0
+#endif
+
 // refill kernel: most waves that share one pixel's samples (launch_render picks K <= this, a power of two)
 #ifndef FLUX_MAX_WAVES_PER_PIXEL
 #define FLUX_MAX_WAVES_PER_PIXEL 4
@@ -115,6 +130,7 @@ struct RenderParams {
     const double2 *pix;   // [S][N] (x,y)                 pixel_sets
     const double2 *disc;  // [S][N] (x,y)                 disc_sets
     const double *hemi;   // hemi_sets: [S][D][N][4] (x,y,z,pad) -- or [S][D][3][N] planes with FLUX_HEMI_AOS4=0
+    const double *gloss;  // [S][N][4] (cos 2 pi x, sin 2 pi x, log2(1 - y), pad) of pixel_sets (FAST glossy lobe)
     const int32_t *rowperm;  // [H][S] sample-set index per (row, col)
     const int32_t *invperm;  // [H][S] its inverse: the column that uses set s in a row
     // work: rows first_row + k*row_stride, k < num_rows

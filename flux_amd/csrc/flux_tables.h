@@ -15,6 +15,9 @@ hipError_t generate_tables(uint64_t seed, uint32_t S, uint32_t D, uint32_t n, ui
 // if d_hemi != nullptr, its to_hemisphere(.., 0.0) image [N][3].  Synchronises `stream`.
 hipError_t generate_sampler_grid(int kind, uint64_t seed, uint32_t n, double *d_xy, double *d_hemi,
                                  hipStream_t stream);
+// FAST glossy lobe factors of the pixel samples: gloss[s][i] = (cos 2 pi x, sin 2 pi x, log2(1 - y), 0) with
+// flux_math.h's functions (render.hip, FAST arithmetic).  Asynchronous on `stream`.
+hipError_t generate_gloss_table(const double2 *pix, size_t count, double *gloss, hipStream_t stream);
 hipError_t hemi_to_aos(size_t SD, size_t N, const double *in, double *out, hipStream_t stream);
 
 // Camera::render (trace.rs:53-97).  variant: FLUX_KERNEL_STATIC / FLUX_KERNEL_REFILL;

@@ -47,6 +47,9 @@
 #ifndef FLUX_BVH_REFILL_AT
 #define FLUX_BVH_REFILL_AT 32     // lanes that must be waiting for shading before the wave leaves traversal
 #endif
+#ifndef FLUX_WPE_SPLIT
+#define FLUX_WPE_SPLIT 4          // waves/SIMD of the split kernel (two path states live in phase A)
+#endif
 #ifndef FLUX_WAVES_PER_EU_FAST
 #define FLUX_WAVES_PER_EU_FAST 5
 #endif
@@ -72,6 +75,27 @@ namespace flux {
 namespace fast {
 #include "render_body.inc"
 }  // namespace fast
+}  // namespace flux
+// FAST glossy-lobe factors of every pixel sample (flux_device.h FLUX_GLOSS_TABLE), compiled with the FAST arithmetic
+// so that the table holds bit for bit what to_unit_hemi would compute inline.
+namespace flux {
+__global__ void gloss_fill_kernel(const double2 *__restrict__ pix, size_t count, double *__restrict__ gloss) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const double2 p = pix[t];
+    double s, c;
+    fastmath::fsincos2pi(p.x, s, c);
+    double *o = gloss + t * 4;
+    o[0] = c;
+    o[1] = s;
+    o[2] = fastmath::flog2(1.0 - p.y);
+    o[3] = 0.0;
+}
+hipError_t generate_gloss_table(const double2 *pix, size_t count, double *gloss, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    gloss_fill_kernel<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream>>>(pix, count, gloss);
+    return hipGetLastError();
+}
 }  // namespace flux
 #undef FLUX_FAST
 #undef FLUX_WPE

@@ -123,6 +123,13 @@ class Renderer:
         _lib.check(_lib.lib.flux_ctx_stats(self._handle(), buf, 1 if reset else 0))
         return dict(zip(STAT_NAMES, [int(x) for x in buf]))
 
+    def stats_raw(self) -> list:
+        """All FLUX_NUM_STATS slots (slots 10.. are reserved: 0 in the product build; experiment builds with
+        -DFLUX_DEBUG_TRIPS count loop trips there, scripts/trip_counts.py)."""
+        buf = (C.c_uint64 * _lib.NUM_STATS)()
+        _lib.check(_lib.lib.flux_ctx_stats(self._handle(), buf, 0))
+        return [int(x) for x in buf]
+
     def set_traversal(self, mode: int):
         """Extension: 0 = BVH (default), 1 = brute force over the triangles."""
         _lib.check(_lib.lib.flux_ctx_set_traversal(self._handle(), mode))

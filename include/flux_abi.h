@@ -173,13 +173,17 @@ int flux_render_sets_device(flux_ctx *ctx, uint64_t first_set, uint64_t set_stri
                             void *d_out_rgb, void *hip_stream);
 
 /* Render-kernel variants (all produce the same image within rounding):
- *   0 = default (currently FLUX_KERNEL_REFILL)
+ *   0 = default (FLUX_KERNEL_SPLIT where it applies, else FLUX_KERNEL_REFILL; STATIC below 64 spp)
  *   1 = FLUX_KERNEL_STATIC: one lane per sample, lanes idle once their path ends
  *   2 = FLUX_KERNEL_REFILL: persistent lanes refilled with the pixel's next
  *       sample by ballot/prefix compaction */
 #define FLUX_KERNEL_DEFAULT 0
 #define FLUX_KERNEL_STATIC 1
 #define FLUX_KERNEL_REFILL 2
+/*   3 = FLUX_KERNEL_SPLIT: FLUX_MATH_FAST, scenes without meshes and with <= 64 spheres, >= 64 spp: primary
+ *       segments (coherent: all lanes of a wave sample one pixel) and secondary segments run in separate passes
+ *       of the wave, joined by an LDS queue; elsewhere it behaves as FLUX_KERNEL_REFILL */
+#define FLUX_KERNEL_SPLIT 3
 int flux_ctx_set_kernel(flux_ctx *ctx, int variant);
 
 /* Arithmetic of the render kernels -- both FP64 end to end, both checked against the oracle at the

@@ -64,7 +64,7 @@ def test_random_scenes_against_the_oracle(flux, oracle_mod, demo1, chunk):
     rng = np.random.default_rng(1000 + chunk)
     for case in range(40):
         sd = random_scene(flux, demo1, rng)
-        n = int(rng.choice([1, 2, 3, 8]))
+        n = int(rng.choice([1, 2, 3, 8, 9]))
         D = int(rng.choice([1, 3, 5, 9]))
         cfg = flux.JobConfiguration(n, D, 50)
         seed = int(rng.integers(1, 1 << 30))
@@ -78,7 +78,7 @@ def test_random_scenes_against_the_oracle(flux, oracle_mod, demo1, chunk):
                 if math == flux.MATH_STRICT and D > 24:
                     continue
                 r.set_math(math)
-                for variant in (flux.KERNEL_STATIC, flux.KERNEL_REFILL):
+                for variant in (flux.KERNEL_STATIC, flux.KERNEL_REFILL, flux.KERNEL_SPLIT):
                     r.set_kernel(variant)
                     r.enable_stats(True)
                     r.stats(reset=True)

@@ -49,7 +49,7 @@ def test_tables_match_oracle(flux, oracle_mod, demo2, n):
 
 @pytest.mark.parametrize("scene_name", ["demo1", "demo2"])
 @pytest.mark.parametrize("n", [1, 3, 4, 8, 9])
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("math", MATH_MODES)
 def test_image_parity_small(flux, oracle_mod, demo1, demo2, scene_name, n, variant, math):
     sd = small_scene(demo1 if scene_name == "demo1" else demo2, 64, 48)
@@ -80,7 +80,7 @@ def test_full_width_rows_parity(flux, oracle_mod, demo2, math):
 def test_stats_match_oracle(flux, oracle_mod, demo2, math):
     sd = small_scene(demo2, 64, 48)
     r, o = _pair(flux, oracle_mod, sd, 8, math=math)
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         r.set_kernel(variant)
         r.enable_stats(True)
         r.stats(reset=True)
@@ -268,7 +268,7 @@ def test_gpu_matches_reference_published_render(flux, demo2, math):
 
 
 @pytest.mark.parametrize("math", MATH_MODES)
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_many_shapes_batches_and_planes(flux, oracle_mod, demo1, math, variant):
     """More shapes than one 32-wide candidate batch (75 spheres incl. nested/overlapping/coincident ones,
     4 planes interleaved in YAML order, every material kind): the sphere scan's batching, the plane/sphere
