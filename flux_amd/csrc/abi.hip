@@ -62,7 +62,7 @@ struct flux_ctx {
     uint32_t n = 0, N = 0, D = 0, S = 0, W = 0, H = 0;
     flux::DevShape *d_shapes = nullptr;
     flux::DevMaterial *d_mats = nullptr;
-    unsigned char *d_fscene = nullptr;  // FAST path: scan spheres | scan planes | hit records
+    unsigned char *d_fscene = nullptr;  // FAST path: scan spheres | scan planes | hit records | f32 filter spheres
     double2 *d_pix = nullptr, *d_disc = nullptr;
     double *d_hemi = nullptr;
     double *d_gloss = nullptr;  // FAST glossy-lobe factors of pixel_sets
@@ -264,6 +264,9 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
         r.fr = m.fr; r.fg = m.fg; r.fb = m.fb;
         r.exponent = m.exponent; r.inv_e1 = m.inv_e1;
         r.shape_kind = d.kind; r.mat_kind = m.kind; r.exp_parity = m.exp_parity; r.orig_id = (int32_t)i;
+        // spheres: |(hit - centre) / radius| = 1 to rounding; planes use the stored normal as is (shapes.rs:135-152)
+        r.unit_normal = d.kind == flux::kShapeSphere ||
+                        std::fabs((d.c0x * d.c0x + d.c0y * d.c0y + d.c0z * d.c0z) - 1.0) <= 4.0 * 2.220446049250313e-16;
         if (d.kind == flux::kShapeSphere) {
             r.cx = d.px; r.cy = d.py; r.cz = d.pz; r.inv_rad = d.inv_rad;
             fsph.push_back(flux::DevScanSphere{d.px, d.py, d.pz, d.rr});
@@ -280,7 +283,28 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     const size_t fs_sph_bytes = (fsph.size() + 1) * sizeof(flux::DevScanSphere);  // +1: the scan reads one record ahead
     const size_t fs_pln_bytes = (fpln.size() + 1) * sizeof(flux::DevScanPlane);
     const size_t fs_rec_bytes = (ns + 1) * sizeof(flux::DevHitRec);
-    std::vector<unsigned char> fscene(fs_sph_bytes + fs_pln_bytes + fs_rec_bytes, 0);
+    // f32 records of the conservative candidate filter (flux_device.h DevScanSphere32): valid while every magnitude
+    // stays far inside f32's range (squares are formed), else the f64 filter is used
+    std::vector<flux::DevScanSphere32> fsph32((fsph.size() + 1) / 2);
+    std::memset(fsph32.data(), 0, fsph32.size() * sizeof(flux::DevScanSphere32));
+    bool filter32_ok = true;
+    for (size_t k = 0; k < fsph.size(); k++) {
+        const flux::DevScanSphere &sp = fsph[k];
+        const double pp = sp.px * sp.px + sp.py * sp.py + sp.pz * sp.pz;
+        if (!(pp < 1e30) || !(sp.rr < 1e30)) filter32_ok = false;
+        const double ppr = (pp - sp.rr) - 8e-6 * (pp + sp.rr) - 1e-30;
+        float f = (float)ppr;
+        if ((double)f > ppr) f = std::nextafterf(f, -INFINITY);  // rounded down: the bias is never reduced
+        flux::DevScanSphere32 &d = fsph32[k / 2];
+        d.px[k & 1] = (float)sp.px;
+        d.py[k & 1] = (float)sp.py;
+        d.pz[k & 1] = (float)sp.pz;
+        d.ppr[k & 1] = f;
+    }
+    const size_t fs_s32_bytes = (fsph32.size() + 4) * sizeof(flux::DevScanSphere32);  // +4 pairs: the filter loads whole groups of 8 spheres
+    std::vector<unsigned char> fscene(fs_sph_bytes + fs_pln_bytes + fs_rec_bytes + fs_s32_bytes, 0);
+    if (!fsph32.empty())
+        std::memcpy(fscene.data() + fs_sph_bytes + fs_pln_bytes + fs_rec_bytes, fsph32.data(), fsph32.size() * sizeof(flux::DevScanSphere32));
     if (!fsph.empty()) std::memcpy(fscene.data(), fsph.data(), fsph.size() * sizeof(flux::DevScanSphere));
     if (!fpln.empty()) std::memcpy(fscene.data() + fs_sph_bytes, fpln.data(), fpln.size() * sizeof(flux::DevScanPlane));
     if (!frec_s.empty()) std::memcpy(fscene.data() + fs_sph_bytes + fs_pln_bytes, frec_s.data(), frec_s.size() * sizeof(flux::DevHitRec));
@@ -429,6 +453,9 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     rp.fsph = reinterpret_cast<const flux::DevScanSphere *>(c->d_fscene);
     rp.fpln = reinterpret_cast<const flux::DevScanPlane *>(c->d_fscene + fs_sph_bytes);
     rp.frec = reinterpret_cast<const flux::DevHitRec *>(c->d_fscene + fs_sph_bytes + fs_pln_bytes);
+    rp.fsph32 = (FLUX_FILTER32 && filter32_ok)
+                    ? reinterpret_cast<const flux::DevScanSphere32 *>(c->d_fscene + fs_sph_bytes + fs_pln_bytes + fs_rec_bytes)
+                    : nullptr;
     rp.bvh_mag = c->bvh.mag;
     rp.set_first = 0;
     rp.set_stride = 1;

@@ -23,12 +23,9 @@
 #define FLUX_GLOSS_TABLE 1
 #endif
 
-// FAST sphere scan: 1 = exact tests of the spheres the ray origin is inside of run last and are skipped when the best hit
-// so far lies strictly inside them (render_body.inc scan_shapes_fast).  Measured on demo2 at 16384 spp: 330 -> 361 ms in
-// the per-lane candidate loop (the second pass costs more loop overhead than the skipped square roots save), so it is
-// off there; the wave-uniform primary scan (scan_shapes_primary) always does it.
-#ifndef FLUX_DEFER_INSIDE
-#define FLUX_DEFER_INSIDE 0
+// FAST sphere scan: 1 = the candidate filter runs in f32 on DevScanSphere32 records (conservative: see there)
+#ifndef FLUX_FILTER32
+#define FLUX_FILTER32 1
 #endif
 
 // refill kernel: most waves that share one pixel's samples (launch_render picks K <= this, a power of two)
@@ -88,6 +85,18 @@ struct DevScanSphere {  // 32 B: one s_load_dwordx8
     double px, py, pz, rr;
 };
 static_assert(sizeof(DevScanSphere) == 32, "DevScanSphere layout");
+// The same spheres for the CONSERVATIVE candidate filter, which runs in f32 (half the issue cost of f64; the exact f64
+// test decides every hit afterwards).  In expanded form hb = o.u - p.u and c = o.o + p.(-2 o) + (p.p - r^2), with the
+// rounding of every term (< 2.1e-6 (o.o + p.p + r^2) in all, render_body.inc) covered by a bias of 8e-6 of the same
+// magnitudes folded into the constants: ppr = (p.p - r^2) - 8e-6 (p.p + r^2) - 1e-30 rounded DOWN here, the ray
+// side scaling o.o by (1 - 8e-6) -- so c is only ever under- and dq = hb^2 - c over-estimated: a superset.
+// Stored as PAIRS (sphere 2j in element 0, 2j+1 in element 1) so that one packed-f32 instruction (v_pk_fma_f32: two
+// floats per lane at the issue cost of one f64 instruction) tests two spheres; a missing partner is all zeros.
+typedef float flux_f2 __attribute__((ext_vector_type(2)));
+struct DevScanSphere32 {  // 32 B per pair: four pairs (8 spheres) per 2 x s_load_dwordx16
+    flux_f2 px, py, pz, ppr;
+};
+static_assert(sizeof(DevScanSphere32) == 32, "DevScanSphere32 layout");
 struct DevScanPlane {   // 64 B
     double px, py, pz;  // point
     double nx, ny, nz;  // normal as stored (never flipped / normalised, shapes.rs:135-152)
@@ -105,7 +114,8 @@ struct DevHitRec {      // 96 B
     double exponent, inv_e1;
     int32_t shape_kind, mat_kind;
     int32_t exp_parity, orig_id;
-    double pad;
+    int32_t unit_normal;  // 1: the hit normal has length 1 to rounding (every sphere; a plane whose stored normal does)
+    int32_t pad;
 };
 static_assert(sizeof(DevHitRec) == 96, "DevHitRec layout");
 
@@ -147,6 +157,7 @@ struct RenderParams {
     const DevScanSphere *fsph;
     const DevScanPlane *fpln;
     const DevHitRec *frec;  // [n_sph + n_pln]
+    const DevScanSphere32 *fsph32;  // [n_sph] f32 candidate-filter records, or nullptr (a coordinate beyond f32's safe range)
     int32_t n_sph, n_pln;
     double bvh_mag;  // largest |coordinate| of any mesh vertex (padding scale of the f32 slab test)
     // work, second axis: sample sets set_first + m*set_stride, m < set_count (default: all S sets).  When

@@ -1,0 +1,24 @@
+#!/bin/bash
+# usage (GPU box): scripts/pmc_variants.sh <tag> <root> <kernel variant> lib1.so lib2.so ...   ("default" = in-tree library)
+TAG=$1; ROOTN=$2; KV=$3; shift 3
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp; cd $REPO
+for LIB in "$@"; do
+  N=$(basename $LIB .so)
+  OUT=$REPO/gpurun_out/pmcv_${TAG}_$N
+  mkdir -p $OUT
+  if [ "$LIB" != "default" ]; then export FLUX_HIP_LIB=$REPO/$LIB; else unset FLUX_HIP_LIB; fi
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT -- python3 scripts/quick_time.py demo2 $ROOTN $KV > $OUT/run.log 2> $OUT/run.err || { tail -5 $OUT/run.err; }
+  python3 - "$OUT" "$N" <<'PY'
+import csv, glob, sys, collections
+agg = collections.defaultdict(list)
+for f in glob.glob(sys.argv[1] + "/*/*counter_collection.csv"):
+    for row in csv.DictReader(open(f)):
+        if "render_" in row["Kernel_Name"]:
+            agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
+a = {k: sum(v) / len(v) for k, v in agg.items()}
+print("%-28s VALU %.4g  ACTIVE_VALU %.4g  SALU %.4g  SMEM %.4g  LDS %.4g  busy %.3f" % (
+    sys.argv[2], a["SQ_INSTS_VALU"], a["SQ_ACTIVE_INST_VALU"], a["SQ_INSTS_SALU"], a["SQ_INSTS_SMEM"], a["SQ_INSTS_LDS"],
+    a["SQ_ACTIVE_INST_VALU"] * 4 / (a["SQ_BUSY_CYCLES"] / 32 * 1024)))
+PY
+done
