@@ -25,6 +25,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # 16384 spp): 1479.9 s on "44 cores" = 5.314 Msamples/s (its timer also spans scene + sample-table construction;
 # the comparable span here is `reference_equivalent_s`)
 PUBLISHED_MSAMPLES_S = 7864.32 / 1479.900397
+# lane-operations one ray segment of demo2 needs at the least (12 sphere tests x 11 + 1.5 exact
+# candidates x 30 + plane 15 + shading 50) -- the yardstick `useful_valu_frac` holds the issued lane slots against
+USEFUL_LANE_OPS_PER_SEGMENT = 242.0
+
+
+# BASELINE.md section 5 configurations -> (scene, sample_root): 2 = demo1 @256 spp, 3 = demo2 @1024 spp, 4 = the headline
+# (demo2 @16384 spp: the workload at every N, it fits one GPU), 5 = the procedural 1M-triangle height field @4096 spp.
+# (1 = demo1 @16 spp on the reference's CPU path: the cpu_baseline leg.)
+CONFIGS = {2: ("demo1", 16), 3: ("demo2", 32), 4: ("demo2", 128), 5: ("hf:1000x500", 64)}
 
 
 def parse():
@@ -32,18 +41,27 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="demo2")
-    ap.add_argument("--root", type=int, default=128, help="sample_root (spp = root^2); 128 = 16384 spp")
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+                    help="a BASELINE.json configuration by number (sets --scene/--root): 2 demo1@256spp, 3 demo2@1024spp, "
+                         "4 demo2@16384spp (the default headline), 5 procedural 1M-triangle height field@4096spp")
+    ap.add_argument("--scene", default=None, help="demo1 | demo2 | hf:NXxNZ (procedural height field)")
+    ap.add_argument("--root", type=int, default=None, help="sample_root (spp = root^2); 128 = 16384 spp")
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--kernel", type=int, default=0, help="0 default, 1 static, 2 refill")
+    ap.add_argument("--kernel", type=int, default=0, help="0 default, 1 static, 2 refill, 3 split")
     ap.add_argument("--math", default="fast", choices=["fast", "strict"],
                     help="render arithmetic (include/flux_abi.h FLUX_MATH_*); both are FP64 and parity-tested")
     ap.add_argument("--shard", default="auto", choices=["auto", "rows", "sets"],
                     help="how the frame is split over GPUs: interleaved rows, or sample sets (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-root", type=int, default=32, help="sample_root of the bounded CPU-baseline sample")
-    return ap.parse_args()
+    ap.add_argument("--cpu-root", type=int, default=None, help="sample_root of the bounded CPU-baseline sample")
+    a = ap.parse_args()
+    scene, root = CONFIGS[a.config if a.config is not None else 4]
+    a.scene = a.scene or scene
+    a.root = a.root or root
+    if a.cpu_root is None:  # ~10-30 s of oracle work on 16 host threads
+        a.cpu_root = 6 if a.scene.startswith("hf:") else 32
+    return a
 
 
 def host_cores():
@@ -80,19 +98,20 @@ def cpu_baseline(sd, depth, seed, cpu_root):
                       f"(row-parallel); table build {t_tables:.2f} s excluded, as for the GPU value"}
 
 
-def load_profile(workload):
-    """The newest committed rocprofv3 PMC summary (profiles/*pmc*.json, scripts/summarize_profile.py) of this
-    workload: (HBM bytes per launch, fraction of SIMD cycles issuing VALU instructions, file name) or Nones."""
+def load_profile(scene_label, kernel_name):
+    """The newest committed rocprofv3 PMC summary (profiles/*pmc*.json, scripts/summarize_profile.py) of this SCENE
+    and KERNEL (any spp: the counters scale with the sample count, so they are carried per sample)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), key=os.path.getmtime, reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
-            if d.get("workload") == workload:
-                return d.get("hbm_bytes_per_launch"), d.get("valu_busy_frac"), os.path.basename(path)
         except Exception:
             continue
-    return None, None, None
+        if d.get("scene") == scene_label and d.get("kernel") == kernel_name and d.get("samples_per_launch"):
+            d["file"] = os.path.basename(path)
+            return d
+    return None
 
 
 def self_launch(n_gpus):
@@ -152,15 +171,16 @@ def main():
     n = a.root
     cfg = flux_amd.JobConfiguration(n, a.depth, 50)
 
+    # Shard by sample set (one pixel per row per owned set: balanced, and each rank keeps the full-frame table
+    # locality, flux_amd/dist.py SetSharder) -- the same code path at every N; `--shard rows` forces row tiles.
+    # A set-sharded rank builds and holds only its own sets' tables (flux_ctx_create_sets).
+    use_sets = a.shard == "sets" or (a.shard == "auto" and n * n >= 64)
     t0 = time.perf_counter()
-    r = flux_amd.Renderer(sd, cfg, seed=a.seed, device=local_rank)
+    r = flux_amd.Renderer(sd, cfg, seed=a.seed, device=local_rank, set_share=(rank, world) if use_sets else None)
     torch.cuda.synchronize()
     t_create = time.perf_counter() - t0
     r.set_kernel(a.kernel)
     r.set_math(flux_amd.MATH_FAST if a.math == "fast" else flux_amd.MATH_STRICT)
-    # Shard by sample set (one pixel per row per owned set: balanced, and each rank keeps the full-frame table
-    # locality, flux_amd/dist.py SetSharder) -- the same code path at every N; `--shard rows` forces row tiles.
-    use_sets = a.shard == "sets" or (a.shard == "auto" and n * n >= 64)
     if use_sets:
         sh = SetSharder(H, W, rank, world, dev, torch.from_numpy(r.row_perm_table()))
         fn = hip_render_sets_fn(r)
@@ -177,23 +197,28 @@ def main():
     for _ in range(a.warmup):
         frame = sh.step(fn)
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    # HIP events on the stream the kernel is launched on (torch's current stream: hip_render_*_fn passes it down, and
+    # there is ONE HIP runtime in the process, flux_amd/_lib.py): render | all_gather | reassembly, per step
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(a.steps)]
     t0 = time.perf_counter()
     for k in range(a.steps):
         ev[k][0].record()
         sh.render(fn)
         ev[k][1].record()
-        frame = sh.gather()
+        sh.collect()
+        ev[k][2].record()
+        frame = sh.assemble()
+        ev[k][3].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = [s.elapsed_time(e) for s, e in ev]
+    phases = [sum(e[j].elapsed_time(e[j + 1]) for e in ev) / max(a.steps, 1) for j in range(3)]
 
-    t = torch.tensor([elapsed, sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed] + phases, dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_max, kernel_ms_max = float(t[0]), float(t[1])
+    elapsed_max, kernel_ms_max, gather_ms_max, assemble_ms_max = [float(x) for x in t]
 
-    # exact path statistics of THIS rank's rows (untimed extra pass) -> algorithmic bytes
+    # exact path statistics of THIS rank's share (untimed extra pass) -> algorithmic bytes
     r.enable_stats(True)
     r.stats(reset=True)
     sh.render(fn)
@@ -212,17 +237,44 @@ def main():
         assert int(tot_samples) == samples, (tot_samples, samples)
         finite = bool(torch.isfinite(frame).all())
         mbar = tot_matte / tot_samples
-        # pixel 16 B + lens 16 B + 24 B per Matte bounce, plus (triangle scenes) the
-        # BVH nodes visited and triangles tested at their laid-out sizes (64 B / 128 B)
-        bytes_per_sample = 32.0 + 24.0 * mbar + (tot_nodes * bvh["node_bytes"] + tot_tris * bvh["tri_bytes"]) / tot_samples
+        gbar = tot_glossy / tot_samples
+        # pixel 16 B + lens 16 B + 24 B per Matte bounce, plus (triangle scenes) the BVH nodes visited
+        # and triangles tested at their laid-out sizes (64 B / 128 B).  (As laid out here a glossy bounce also reads 24 B
+        # of tabulated lobe factors: reported beside it, not counted in `achieved`.)
+        table_bytes = 32.0 + 24.0 * mbar
+        bvh_bytes = (tot_nodes * bvh["node_bytes"] + tot_tris * bvh["tri_bytes"]) / tot_samples
+        bytes_per_sample = table_bytes + bvh_bytes
         # the dominant kernel's launch on rank 0 covers samples/world camera paths + its share of the framebuffer
-        alg_bytes_launch = (samples / world) * bytes_per_sample + (H * W / world) * 24.0
-        achieved = alg_bytes_launch / (kernel_ms_max * 1e-3) / 1e9
+        samples_launch = samples / world
+        alg_bytes_launch = samples_launch * bytes_per_sample + (H * W / world) * 24.0
+        alg_gbs = alg_bytes_launch / (kernel_ms_max * 1e-3) / 1e9
         workload = f"{scene_label} {W}x{H} at {n * n} spp (sample_root {n}), depth {a.depth}, seed {a.seed}"
-        refill = a.kernel in (0, 2) and n * n >= 64
-        kernel_name = ("render_bvh_kernel" if refill and a.math == "fast" and bvh["triangles"] > 0 else
-                       "render_refill_kernel" if refill else "render_static_kernel")
-        traffic, valu_busy, profile_name = load_profile(workload)
+        dyn = n * n >= 64 and a.kernel != 1
+        if dyn and a.math == "fast" and bvh["triangles"] > 0:
+            kernel_name = "render_bvh_kernel"
+        elif dyn and a.math == "fast" and a.kernel in (0, 3) and n * n >= (256 if a.kernel == 0 else 64) and bvh["triangles"] == 0:
+            kernel_name = "render_split_kernel"
+        else:
+            kernel_name = "render_refill_kernel" if dyn else "render_static_kernel"
+        prof = load_profile(scene_label, kernel_name)
+        # counters of the committed rocprofv3 PMC passes of this scene + kernel, carried per sample
+        scale = samples_launch / prof["samples_per_launch"] if prof else None
+        traffic = prof["hbm_bytes_per_launch"] * scale if prof and prof.get("hbm_bytes_per_launch") else None
+        traffic_gbs = traffic / (kernel_ms_max * 1e-3) / 1e9 if traffic else None
+        # A roofline fraction above 1 is meaningless: where the algorithmic byte count (every node / triangle record a
+        # lane reads, mostly served by L1 / L2 / Infinity Cache) exceeds what HBM could deliver, the MEASURED memory-side
+        # traffic is the figure held against the HBM peak.
+        if alg_gbs <= HBM_PEAK_GBS:
+            achieved, basis = alg_gbs, "algorithmic bytes (SURVEY.md 8d) / kernel time"
+        elif traffic_gbs is not None:
+            achieved, basis = traffic_gbs, ("measured memory-side traffic (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 PMC, "
+                                            f"profiles/{prof['file']}) / kernel time: the algorithmic figure "
+                                            f"({alg_gbs:.0f} GB/s, cache-served) exceeds the HBM peak")
+        else:
+            achieved, basis = None, "algorithmic figure exceeds the HBM peak and no committed PMC profile matches this scene"
+        valu_insts = prof["valu_insts_per_launch"] * scale if prof and prof.get("valu_insts_per_launch") else None
+        # FP64-VALU issue ceiling: 256 CU x 4 SIMD, one wave-instruction per 4 cycles at 2.4 GHz = 614.4 G/s
+        issue_peak = 256 * 4 * 2.4e9 / 4
         out = {
             "metric": "Msamples/sec on demo2.yml (fixed spp)",
             "value": round(samples * a.steps / elapsed_max / 1e6, 3),
@@ -237,37 +289,55 @@ def main():
                             if a.scene == "demo2" and n == 128 else None),
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": workload, "kernel": kernel_name.replace("render_", "").replace("_kernel", ""),
+            "config": {"workload": workload, "scene": scene_label, "kernel": kernel_name.replace("render_", "").replace("_kernel", ""),
                        "math": a.math,
-                       "parallelism": (f"pixel-set tiles (one pixel per row per owned sample set) over {world} GPU(s), "
-                                       "1 all_gather" if use_sets else
+                       "parallelism": (f"pixel-set tiles (one pixel per row per owned sample set; each rank holds only its "
+                                       f"sets' tables) over {world} GPU(s), 1 all_gather" if use_sets else
                                        f"row-interleaved image tiles over {world} GPU(s), 1 all_gather"),
                        "finite": finite},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "valu_busy_frac": None if valu_busy is None else round(valu_busy, 4), "profile": profile_name,
+            "step_breakdown_ms": {"render": round(kernel_ms_max, 3), "all_gather": round(gather_ms_max, 3),
+                                  "reassembly": round(assemble_ms_max, 3),
+                                  "note": "HIP events on the launch stream, mean over steps, max over ranks"},
+            "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 6),
+                         "traffic": traffic, "basis": basis,
+                         "algorithmic_gbs": round(alg_gbs, 3),
+                         "traffic_gbs": None if traffic_gbs is None else round(traffic_gbs, 3),
+                         "profile": prof["file"] if prof else None,
                          "kernel": kernel_name,
-                         "kernel_ms": round(kernel_ms_max, 3), "bytes_per_sample": round(bytes_per_sample, 3),
+                         "kernel_ms": round(kernel_ms_max, 3), "samples_per_launch": samples_launch,
+                         "bytes_per_sample": round(bytes_per_sample, 3),
+                         "bytes_per_sample_as_laid_out": round(bytes_per_sample + 24.0 * gbar, 3),
+                         # what actually bounds the analytic kernels: FP64-rate VALU issue (every VALU instruction, packed
+                         # f32 included, takes 4 cycles of a SIMD) -- from the committed PMC profile of this scene
+                         "fp64_issue_frac": (None if valu_insts is None else
+                                             round(valu_insts / (kernel_ms_max * 1e-3) / issue_peak, 4)),
+                         "valu_busy_frac": prof.get("valu_busy_frac") if prof else None,
+                         "lanes_active_frac": prof.get("lanes_active_frac") if prof else None,
+                         "useful_valu_frac": (None if valu_insts is None or bvh["triangles"] else
+                                              round(USEFUL_LANE_OPS_PER_SEGMENT * tot_segments / world / (64.0 * valu_insts), 4)),
                          "matte_bounces_per_sample": round(mbar, 5),
                          "segments_per_sample": round(tot_segments / tot_samples, 5),
-                         "glossy_bounces_per_sample": round(tot_glossy / tot_samples, 5),
+                         "glossy_bounces_per_sample": round(gbar, 5),
                          "bvh_nodes_per_sample": round(tot_nodes / tot_samples, 3),
                          "tris_tested_per_sample": round(tot_tris / tot_samples, 3),
                          "misses": int(tot_miss),
-                         "note": "FP64 path tracer: analytic shapes live in SGPRs; the sample tables (and, for "
-                                 "triangle scenes, BVH nodes/triangles) are the only streamed data; bytes are "
-                                 "the algorithmic figure, not inflated; with the set-grouped pixel order nearly all of them are "
-                                 "served by the XCD L2s, `traffic` (committed rocprofv3 PMC pass) is what reached the "
-                                 "memory side.  The kernel is FP64-VALU bound (SQ_ACTIVE_INST_VALU 96% of SIMD cycles, "
-                                 "profiles/).  For triangle scenes the algorithmic "
-                                 "figure counts every node/triangle record a lane reads (SURVEY 8d), most of "
-                                 "which are served by L1/L2/Infinity Cache, so it can exceed the HBM peak; "
-                                 "`traffic` is what reached the memory side"},
+                         "note": "FP64 path tracer: analytic shapes live in SGPRs; the sample tables (and, for triangle "
+                                 "scenes, BVH nodes/triangles) are the only streamed data; bytes are the algorithmic figure, "
+                                 "not inflated; with the set-grouped pixel order nearly all table bytes are served by the XCD "
+                                 "L2s (`traffic`: what reached the memory side).  The analytic kernels are VALU-issue bound "
+                                 "(valu_busy_frac); lanes_active_frac = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU); "
+                                 "useful_valu_frac = model lane-operations (DESIGN.md section 4) / issued lane slots"},
             "ctx_create_ms": round(t_create * 1e3, 1),
             "reference_equivalent_s": round(t_create + elapsed_max / a.steps, 4),
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, a.depth, a.seed, a.cpu_root)
+            if a.scene.startswith("hf:"):
+                # the CPU checker scans every triangle per ray (it DEFINES what the BVH must reproduce): ~5 ms per ray on
+                # a 1M-triangle mesh, so no bounded sample of this workload is meaningful; the headline line carries it
+                out["cpu_baseline"] = None
+            else:
+                out["cpu_baseline"] = cpu_baseline(sd, a.depth, a.seed, a.cpu_root)
         print(json.dumps(out), flush=True)
     r.close()
     if world > 1:

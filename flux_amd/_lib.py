@@ -70,6 +70,8 @@ SYMBOLS = {
     "flux_device_count": (C.c_int, []),
     "flux_ctx_create": (C.c_int, [C.POINTER(FluxSceneDesc), C.POINTER(FluxJobCfg), C.c_uint64, C.c_int,
                                   C.POINTER(_P)]),
+    "flux_ctx_create_sets": (C.c_int, [C.POINTER(FluxSceneDesc), C.POINTER(FluxJobCfg), C.c_uint64, C.c_int, C.c_uint64,
+                                       C.c_uint64, C.POINTER(_P)]),
     "flux_ctx_destroy": (None, [_P]),
     "flux_render_rows": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]),
     "flux_render_rows_device": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P]),

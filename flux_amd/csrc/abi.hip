@@ -60,6 +60,7 @@ struct flux_ctx {
     flux::RenderParams rp{};  // camera + table pointers; work fields set per launch
     uint64_t seed = 0;
     uint32_t n = 0, N = 0, D = 0, S = 0, W = 0, H = 0;
+    flux::SetRange sets{0, 1, 0};  // sets with tables in this context (all S unless created by flux_ctx_create_sets)
     flux::DevShape *d_shapes = nullptr;
     flux::DevMaterial *d_mats = nullptr;
     unsigned char *d_fscene = nullptr;  // FAST path: scan spheres | scan planes | hit records | f32 filter spheres
@@ -153,8 +154,16 @@ static void fill_material(flux::DevMaterial &dm, const flux_material &m) {
 
 int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint64_t seed, int device,
                     flux_ctx **out) {
+    return flux_ctx_create_sets(scene, cfg, seed, device, 0, 1, out);
+}
+
+int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint64_t seed, int device,
+                         uint64_t first_set, uint64_t set_stride, flux_ctx **out) {
     if (!scene || !cfg || !out) return fail(FLUX_E_INVALID, "flux_ctx_create: null argument");
     *out = nullptr;
+    if (set_stride < 1 || first_set >= set_stride)
+        return fail(FLUX_E_INVALID, "sample-set share: need set_stride >= 1 and first_set < set_stride, got %llu / %llu",
+                    (unsigned long long)first_set, (unsigned long long)set_stride);
     if (cfg->sample_root < 1 || cfg->sample_root > 4096)
         return fail(FLUX_E_INVALID, "sample_root must be in [1,4096], got %llu",
                     (unsigned long long)cfg->sample_root);
@@ -219,6 +228,10 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     c->W = (uint32_t)scene->image_width;
     c->H = (uint32_t)scene->image_height;
     c->S = c->W;  // workers.rs:50: num_sets = image_width
+    // the sets this context holds tables for: all of them, or one rank's share of a set-sharded render
+    c->sets.first = (uint32_t)first_set;
+    c->sets.stride = (uint32_t)set_stride;
+    c->sets.count = first_set < c->S ? (uint32_t)((c->S - first_set + set_stride - 1) / set_stride) : 0u;
 
     // ---- Scene::from_data: per-shape constants -------------------------------
     const size_t ns = (size_t)scene->num_shapes;
@@ -393,8 +406,9 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     rp.num_sets = c->S;
 
     // ---- HBM allocations ------------------------------------------------------
-    const size_t pix_bytes = (size_t)c->S * c->N * sizeof(double2);
-    const size_t hemi_bytes = (size_t)c->S * c->D * c->N * flux::kHemiDoubles * sizeof(double);
+    const size_t own = c->sets.count ? c->sets.count : 1;  // a share past the last set holds nothing (allocate one slot)
+    const size_t pix_bytes = own * c->N * sizeof(double2);
+    const size_t hemi_bytes = own * c->D * c->N * flux::kHemiDoubles * sizeof(double);
     const size_t perm_bytes = (size_t)c->H * c->S * sizeof(int32_t);
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) {
@@ -426,9 +440,9 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     // ---- MasterSampleSets::new on the device (sampling.rs:13-33) --------------
     if (e == hipSuccess)
-        e = flux::generate_tables(seed, c->S, c->D, c->n, c->H, c->d_pix, c->d_disc, c->d_hemi, c->d_rowperm, c->d_invperm, nullptr);
+        e = flux::generate_tables(seed, c->S, c->sets, c->D, c->n, c->H, c->d_pix, c->d_disc, c->d_hemi, c->d_rowperm, c->d_invperm, nullptr);
     if (e == hipSuccess && FLUX_GLOSS_TABLE) {
-        e = flux::generate_gloss_table(c->d_pix, (size_t)c->S * c->N, c->d_gloss, nullptr);
+        e = flux::generate_gloss_table(c->d_pix, (size_t)c->sets.count * c->N, c->d_gloss, nullptr);
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     }
     if (e != hipSuccess) {
@@ -461,11 +475,15 @@ int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint6
     rp.set_stride = 1;
     rp.set_count = (int32_t)c->S;
     rp.out_by_set = 0;
+    rp.slot_first = 0;
+    rp.slot_stride = 1;
     rp.n_sph = (int32_t)fsph.size();
     rp.n_pln = (int32_t)fpln.size();
     *out = c;
     return FLUX_OK;
 }
+
+static bool holds_all_sets(const flux_ctx *c) { return c->sets.stride == 1 && c->sets.first == 0; }
 
 int flux_ctx_set_kernel(flux_ctx *ctx, int variant) {
     if (!ctx) return fail(FLUX_E_INVALID, "null context");
@@ -487,6 +505,7 @@ int flux_debug_shade(flux_ctx *ctx, uint64_t n, const double *rays, uint64_t dep
     if (!ctx || !rays || !out_rgb) return fail(FLUX_E_INVALID, "null argument");
     if (n == 0) return FLUX_OK;
     if (n > (1u << 24)) return fail(FLUX_E_INVALID, "too many rays");
+    if (!holds_all_sets(ctx)) return fail(FLUX_E_INVALID, "this context holds a share of the sample sets only (flux_ctx_create_sets)");
     if (depth < 1 || set_index >= ctx->S || sample_index >= ctx->N)
         return fail(FLUX_E_INVALID, "depth >= 1, set_index < %u and sample_index < %u required", ctx->S, ctx->N);
     if (ctx->math == FLUX_MATH_STRICT && (size_t)ctx->D * 4 * 64 * sizeof(double) > 60 * 1024)
@@ -568,6 +587,9 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
     if (num_rows == 0) return FLUX_OK;
     if (!d_out_rgb) return fail(FLUX_E_INVALID, "null output pointer");
     if (row_stride < 1) return fail(FLUX_E_INVALID, "row_stride must be >= 1");
+    if (!holds_all_sets(ctx))  // every row uses every sample set (trace.rs:64-69)
+        return fail(FLUX_E_INVALID, "rendering rows needs all sample sets; this context holds the share %u + k*%u "
+                    "(flux_ctx_create_sets): use flux_render_sets_device", ctx->sets.first, ctx->sets.stride);
     if (first_row >= ctx->H || first_row + (num_rows - 1) * row_stride >= ctx->H)
         return fail(FLUX_E_INVALID, "rows %llu + k*%llu (k<%llu) exceed image height %u",
                     (unsigned long long)first_row, (unsigned long long)row_stride,
@@ -609,6 +631,11 @@ int flux_render_sets_device(flux_ctx *ctx, uint64_t first_set, uint64_t set_stri
                     (unsigned long long)set_stride, (unsigned long long)num_sets, ctx->S);
     if (ctx->N < 64 || ctx->variant == FLUX_KERNEL_STATIC || !FLUX_SET_GROUPED)
         return fail(FLUX_E_INVALID, "set-sharded rendering needs the refill kernel (sample_root^2 >= 64)");
+    // every requested set must have its tables here: first_set + m*set_stride = sets.first + (slot_first + m*slot_stride)*sets.stride
+    if (first_set < ctx->sets.first || (first_set - ctx->sets.first) % ctx->sets.stride != 0 ||
+        (num_sets > 1 && set_stride % ctx->sets.stride != 0))
+        return fail(FLUX_E_INVALID, "sets %llu + k*%llu are not all among this context's share %u + k*%u (flux_ctx_create_sets)",
+                    (unsigned long long)first_set, (unsigned long long)set_stride, ctx->sets.first, ctx->sets.stride);
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(FLUX_E_DEVICE, "hipSetDevice(%d) failed", ctx->device);
     hipStream_t stream = (hipStream_t)hip_stream;
@@ -621,6 +648,8 @@ int flux_render_sets_device(flux_ctx *ctx, uint64_t first_set, uint64_t set_stri
     p.set_stride = (int32_t)set_stride;
     p.set_count = (int32_t)num_sets;
     p.out_by_set = 1;
+    p.slot_first = (int32_t)((first_set - ctx->sets.first) / ctx->sets.stride);
+    p.slot_stride = (int32_t)(set_stride / ctx->sets.stride);
     p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
     if (ctx->math == FLUX_MATH_STRICT && (size_t)ctx->D * 4 * 64 * FLUX_MAX_WAVES_PER_PIXEL * sizeof(double) > 60 * 1024)
@@ -705,7 +734,7 @@ int flux_ctx_stats(flux_ctx *ctx, uint64_t out[FLUX_NUM_STATS], int reset) {
 int flux_ctx_copy_table(flux_ctx *ctx, int which, double *out, uint64_t out_doubles) {
     if (!ctx || !out) return fail(FLUX_E_INVALID, "null argument");
     DeviceGuard guard(ctx->device);
-    const size_t SN = (size_t)ctx->S * ctx->N;
+    const size_t SN = (size_t)ctx->sets.count * ctx->N;  // the sets held here, in slot order
     if (which == FLUX_TABLE_PIXEL || which == FLUX_TABLE_DISC) {
         if (out_doubles < SN * 2) return fail(FLUX_E_INVALID, "output too small: need %zu doubles", SN * 2);
         HIP_TRY(hipMemcpy(out, which == FLUX_TABLE_PIXEL ? ctx->d_pix : ctx->d_disc, SN * 2 * sizeof(double),
@@ -717,7 +746,7 @@ int flux_ctx_copy_table(flux_ctx *ctx, int which, double *out, uint64_t out_doub
         if (out_doubles < total) return fail(FLUX_E_INVALID, "output too small: need %zu doubles", total);
         double *tmp = nullptr;
         HIP_TRY(hipMalloc((void **)&tmp, total * sizeof(double)));
-        hipError_t e = flux::hemi_to_aos((size_t)ctx->S * ctx->D, ctx->N, ctx->d_hemi, tmp, nullptr);
+        hipError_t e = flux::hemi_to_aos((size_t)ctx->sets.count * ctx->D, ctx->N, ctx->d_hemi, tmp, nullptr);
         if (e == hipSuccess) e = hipMemcpy(out, tmp, total * sizeof(double), hipMemcpyDeviceToHost);
         (void)hipFree(tmp);
         if (e != hipSuccess) return fail(FLUX_E_DEVICE, "hemi copy: %s", hipGetErrorString(e));

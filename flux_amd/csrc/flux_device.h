@@ -119,6 +119,11 @@ struct DevHitRec {      // 96 B
 };
 static_assert(sizeof(DevHitRec) == 96, "DevHitRec layout");
 
+// The sample sets a context holds tables for: local slot m = global set first + m * stride, m < count.
+struct SetRange {
+    uint32_t first, stride, count;
+};
+
 // Kernel argument block (by value -> kernarg segment -> scalar loads).
 struct RenderParams {
     // camera (trace.rs:44-60, scene.rs:28-35)
@@ -164,6 +169,9 @@ struct RenderParams {
     // out_by_set != 0 the pixel of (local row k, local set m) is written to out[(k*set_count + m)*3]
     // instead of out[(k*W + col)*3] (flux_render_sets_device).
     int32_t set_first, set_stride, set_count, out_by_set;
+    // table slot of set set_first + m*set_stride: slot_first + m*slot_stride (equal to the set index itself unless the
+    // context holds only a subset of the sets, flux_ctx_create_sets).  The kernels address pix/disc/hemi/gloss by slot.
+    int32_t slot_first, slot_stride;
 };
 
 }  // namespace flux

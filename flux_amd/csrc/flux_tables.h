@@ -6,9 +6,10 @@
 
 namespace flux {
 
-// MasterSampleSets::new (sampling.rs:13-33) + shuffle_indices for all H rows
-// (sampling.rs:35-40), generated on the device.  Synchronises `stream`.
-hipError_t generate_tables(uint64_t seed, uint32_t S, uint32_t D, uint32_t n, uint32_t H,
+// MasterSampleSets::new (sampling.rs:13-33) for the sets of `sets` (slot m = global set first + m * stride; all S of
+// them for {0, 1, S}) + shuffle_indices for all H rows and all S sets (sampling.rs:35-40), generated on the device.
+// Synchronises `stream`.
+hipError_t generate_tables(uint64_t seed, uint32_t S, SetRange sets, uint32_t D, uint32_t n, uint32_t H,
                            double2 *pix, double2 *disc, double *hemi, int32_t *rowperm, int32_t *invperm,
                            hipStream_t stream);
 // One set of a samplers-crate generator (0 regular, 1 jittered, 2 multi-jittered, 3 correlated MJ) and,

@@ -21,21 +21,26 @@ namespace flux {
 // ---- permutations --------------------------------------------------------
 // perms layout (uint16): CMJ kind : [S][2][n]            (0 = x_idxs, 1 = y_idxs)
 //                        MJ (hemi): [S][D][2n][n]         (0..n-1 = y-shuffle of row i, n..2n-1 = x-shuffle of column k)
-__global__ void cmj_perm_kernel(uint64_t seed, uint64_t kind, uint32_t S, uint32_t n, uint16_t *perms) {
+// Tables may hold a SUBSET of the sample sets (a rank of a set-sharded render builds only the sets it owns): local
+// slot m holds global set sets.first + m * sets.stride; the RNG streams are keyed by the GLOBAL index, so a set's
+// contents do not depend on which context builds it.
+__device__ __forceinline__ uint32_t global_set(SetRange sets, uint32_t slot) { return sets.first + slot * sets.stride; }
+
+__global__ void cmj_perm_kernel(uint64_t seed, uint64_t kind, SetRange sets, uint32_t n, uint16_t *perms) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= S * 2u) return;
+    if (t >= sets.count * 2u) return;
     uint32_t s = t >> 1, which = t & 1u;
-    shuffle_iota(stream_key(seed, kind, s, 0, 1 + which), perms + (size_t)t * n, n);
+    shuffle_iota(stream_key(seed, kind, global_set(sets, s), 0, 1 + which), perms + (size_t)t * n, n);
 }
 
-__global__ void mj_perm_kernel(uint64_t seed, uint32_t S, uint32_t D, uint32_t n, uint16_t *perms) {
+__global__ void mj_perm_kernel(uint64_t seed, SetRange sets, uint32_t D, uint32_t n, uint16_t *perms) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t total = (size_t)S * D * 2u * n;
+    size_t total = (size_t)sets.count * D * 2u * n;
     if (t >= total) return;
     uint32_t sub = (uint32_t)(t % (2u * n));
     size_t sd = t / (2u * n);
     uint32_t d = (uint32_t)(sd % D), s = (uint32_t)(sd / D);
-    shuffle_iota(stream_key(seed, kKindHemi, s, d, 1 + sub), perms + t * n, n);
+    shuffle_iota(stream_key(seed, kKindHemi, global_set(sets, s), d, 1 + sub), perms + t * n, n);
 }
 
 // shuffle_indices (sampling.rs:35-40) for every image row, keyed by (seed,row)
@@ -107,27 +112,27 @@ __device__ __forceinline__ void unit_hemi_e0(double2 q, double &ox, double &oy, 
 }
 
 // pixel_sets (sampling.rs:16-17) and disc_sets (sampling.rs:19-21)
-__global__ void cmj_fill_kernel(uint64_t seed, uint64_t kind, uint32_t S, uint32_t n,
+__global__ void cmj_fill_kernel(uint64_t seed, uint64_t kind, SetRange sets, uint32_t n,
                                 const uint16_t *__restrict__ perms, double2 *__restrict__ out) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t N = (size_t)n * n;
-    if (t >= (size_t)S * N) return;
+    if (t >= (size_t)sets.count * N) return;
     uint32_t s = (uint32_t)(t / N);
     uint32_t p = (uint32_t)(t % N);
     uint32_t i = p / n, k = p % n;
     const uint16_t *xp = perms + ((size_t)s * 2) * n;
     const uint16_t *yp = xp + n;
-    double2 q = mj_point(stream_key(seed, kind, s, 0, kSubJitter), n, i, k, xp[i], yp[k]);
+    double2 q = mj_point(stream_key(seed, kind, global_set(sets, s), 0, kSubJitter), n, i, k, xp[i], yp[k]);
     out[t] = (kind == kKindDisc) ? to_disc(q) : q;
 }
 
 // hemi_sets: to_hemisphere(grid_multi_jittered(n), 0.0) per (set, depth)
 // (sampling.rs:23-29, lib.rs:129-142), stored SoA [S][D][3][N].
-__global__ void hemi_fill_kernel(uint64_t seed, uint32_t S, uint32_t D, uint32_t n,
+__global__ void hemi_fill_kernel(uint64_t seed, SetRange sets, uint32_t D, uint32_t n,
                                  const uint16_t *__restrict__ perms, double *__restrict__ out) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t N = (size_t)n * n;
-    if (t >= (size_t)S * D * N) return;
+    if (t >= (size_t)sets.count * D * N) return;
     size_t sd = t / N;
     uint32_t p = (uint32_t)(t % N);
     uint32_t d = (uint32_t)(sd % D), s = (uint32_t)(sd / D);
@@ -142,7 +147,7 @@ __global__ void hemi_fill_kernel(uint64_t seed, uint32_t S, uint32_t D, uint32_t
     uint32_t yk = pb[(size_t)i * n + k];        // y-shuffle of row i, element k
     uint32_t xi = pb[((size_t)n + k) * n + i];  // x-shuffle of column k, element i
 #endif
-    double2 q = mj_point(stream_key(seed, kKindHemi, s, d, kSubJitter), n, i, k, xi, yk);
+    double2 q = mj_point(stream_key(seed, kKindHemi, global_set(sets, s), d, kSubJitter), n, i, k, xi, yk);
     double pu, pv, pw;
     unit_hemi_e0(q, pu, pv, pw);
 #if FLUX_HEMI_AOS4
@@ -217,10 +222,10 @@ hipError_t generate_sampler_grid(int kind, uint64_t seed, uint32_t n, double *d_
     hipError_t e = hipSuccess;
     if (kind == 2) {
         if ((e = hipMalloc(&perms, (size_t)2 * n * n * sizeof(uint16_t))) != hipSuccess) return e;
-        mj_perm_kernel<<<blocks_for((size_t)2 * n, 64), 64, 0, stream>>>(seed, 1, 1, n, perms);
+        mj_perm_kernel<<<blocks_for((size_t)2 * n, 64), 64, 0, stream>>>(seed, SetRange{0, 1, 1}, 1, n, perms);
     } else if (kind == 3) {
         if ((e = hipMalloc(&perms, (size_t)2 * n * sizeof(uint16_t))) != hipSuccess) return e;
-        cmj_perm_kernel<<<1, 64, 0, stream>>>(seed, kKindPixel, 1, n, perms);
+        cmj_perm_kernel<<<1, 64, 0, stream>>>(seed, kKindPixel, SetRange{0, 1, 1}, n, perms);
     }
     sampler_grid_kernel<<<blocks_for((size_t)n * n, 256), 256, 0, stream>>>(kind, seed, n, perms, d_xy, d_hemi);
     e = hipGetLastError();
@@ -229,14 +234,15 @@ hipError_t generate_sampler_grid(int kind, uint64_t seed, uint32_t n, double *d_
     return e != hipSuccess ? e : e2;
 }
 
-hipError_t generate_tables(uint64_t seed, uint32_t S, uint32_t D, uint32_t n, uint32_t H,
+hipError_t generate_tables(uint64_t seed, uint32_t S, SetRange sets, uint32_t D, uint32_t n, uint32_t H,
                            double2 *pix, double2 *disc, double *hemi, int32_t *rowperm, int32_t *invperm,
                            hipStream_t stream) {
     const size_t N = (size_t)n * n;
+    const uint32_t So = sets.count;  // sets held by this context
     uint16_t *cmj_perms = nullptr, *mj_perms = nullptr;
     hipError_t e;
-    size_t cmj_elems = (size_t)S * 2 * n;
-    size_t mj_elems = (size_t)S * D * 2 * n * n;
+    size_t cmj_elems = (size_t)So * 2 * n;
+    size_t mj_elems = (size_t)So * D * 2 * n * n;
     if ((e = hipMalloc(&cmj_perms, 2 * cmj_elems * sizeof(uint16_t))) != hipSuccess) return e;
     if ((e = hipMalloc(&mj_perms, mj_elems * sizeof(uint16_t))) != hipSuccess) {
         (void)hipFree(cmj_perms);
@@ -244,14 +250,14 @@ hipError_t generate_tables(uint64_t seed, uint32_t S, uint32_t D, uint32_t n, ui
     }
     uint16_t *pix_perms = cmj_perms, *disc_perms = cmj_perms + cmj_elems;
     const unsigned bs = 256;
-    cmj_perm_kernel<<<blocks_for((size_t)S * 2, 64), 64, 0, stream>>>(seed, kKindPixel, S, n, pix_perms);
-    cmj_perm_kernel<<<blocks_for((size_t)S * 2, 64), 64, 0, stream>>>(seed, kKindDisc, S, n, disc_perms);
-    mj_perm_kernel<<<blocks_for((size_t)S * D * 2 * n, bs), bs, 0, stream>>>(seed, S, D, n, mj_perms);
-    row_perm_kernel<<<blocks_for(H, 64), 64, 0, stream>>>(seed, H, S, rowperm);
+    cmj_perm_kernel<<<blocks_for((size_t)So * 2, 64), 64, 0, stream>>>(seed, kKindPixel, sets, n, pix_perms);
+    cmj_perm_kernel<<<blocks_for((size_t)So * 2, 64), 64, 0, stream>>>(seed, kKindDisc, sets, n, disc_perms);
+    mj_perm_kernel<<<blocks_for((size_t)So * D * 2 * n, bs), bs, 0, stream>>>(seed, sets, D, n, mj_perms);
+    row_perm_kernel<<<blocks_for(H, 64), 64, 0, stream>>>(seed, H, S, rowperm);  // always all S sets: who uses which
     inv_perm_kernel<<<blocks_for((size_t)H * S, bs), bs, 0, stream>>>(H, S, rowperm, invperm);
-    cmj_fill_kernel<<<blocks_for((size_t)S * N, bs), bs, 0, stream>>>(seed, kKindPixel, S, n, pix_perms, pix);
-    cmj_fill_kernel<<<blocks_for((size_t)S * N, bs), bs, 0, stream>>>(seed, kKindDisc, S, n, disc_perms, disc);
-    hemi_fill_kernel<<<blocks_for((size_t)S * D * N, bs), bs, 0, stream>>>(seed, S, D, n, mj_perms, hemi);
+    cmj_fill_kernel<<<blocks_for((size_t)So * N, bs), bs, 0, stream>>>(seed, kKindPixel, sets, n, pix_perms, pix);
+    cmj_fill_kernel<<<blocks_for((size_t)So * N, bs), bs, 0, stream>>>(seed, kKindDisc, sets, n, disc_perms, disc);
+    hemi_fill_kernel<<<blocks_for((size_t)So * D * N, bs), bs, 0, stream>>>(seed, sets, D, n, mj_perms, hemi);
     e = hipGetLastError();
     hipError_t e2 = hipStreamSynchronize(stream);
     (void)hipFree(cmj_perms);

@@ -48,13 +48,21 @@ class FrameSharder:
         if self.count:
             render_fn(self.first, self.stride, self.count, self.local)
 
-    def gather(self) -> torch.Tensor:
-        """One collective; returns the assembled [H][W][3] frame (a view, valid on every rank)."""
+    def collect(self):
+        """The ONE collective of a frame: all_gather of every rank's row buffer (RCCL over xGMI on GPUs)."""
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
+
+    def assemble(self) -> torch.Tensor:
+        """The gathered buffers in image order: [H][W][3] (a view, valid on every rank)."""
         if self.world == 1:
             return self.local[: self.height]
-        dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
         # gathered[g][k] is image row k*G + g  ->  [k][g] order is image order
         return self.gathered.permute(1, 0, 2, 3).reshape(self.rmax * self.world, self.width, 3)[: self.height]
+
+    def gather(self) -> torch.Tensor:
+        self.collect()
+        return self.assemble()
 
     def step(self, render_fn) -> torch.Tensor:
         self.render(render_fn)
@@ -90,15 +98,22 @@ class SetSharder:
         if self.count:
             render_fn(self.rank, self.world, self.count, self.render_buf)
 
-    def gather(self) -> torch.Tensor:
+    def collect(self):
+        """The ONE collective of a frame: all_gather of every rank's [H][sets][3] share."""
         if self.local is not self.render_buf:
             self.local[:, : self.count] = self.render_buf
-        if self.world == 1:
-            src = self.local.unsqueeze(0)
-        else:
+        if self.world > 1:
             dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
-            src = self.gathered
+
+    def assemble(self) -> torch.Tensor:
+        """One indexed read with the row permutation: pixel (r, c) uses set s = rowperm[r][c], rendered by rank s % G
+        as its (s // G)-th set -- the counterpart of ImageBuilder placing rows (manager.rs:316-324)."""
+        src = self.local.unsqueeze(0) if self.world == 1 else self.gathered
         return src[self._g, self._r, self._m]  # [H][W][3]
+
+    def gather(self) -> torch.Tensor:
+        self.collect()
+        return self.assemble()
 
     def step(self, render_fn) -> torch.Tensor:
         self.render(render_fn)

@@ -18,7 +18,10 @@ STAT_NAMES = ("samples", "segments", "matte_bounces", "glossy_bounces", "specula
 
 
 class Renderer:
-    def __init__(self, scene_data: SceneData, config: JobConfiguration, seed: int = 1, device: int = 0):
+    def __init__(self, scene_data: SceneData, config: JobConfiguration, seed: int = 1, device: int = 0,
+                 set_share=None):
+        """`set_share` = (first_set, set_stride): hold the sample tables of this rank's sets only
+        (flux_ctx_create_sets; render with render_sets_device)."""
         self.scene_data = scene_data
         self.config = config
         self.seed = int(seed)
@@ -28,8 +31,9 @@ class Renderer:
         self._desc = SceneDesc(scene_data)
         cfg = _lib.FluxJobCfg(config.sample_root, config.max_trace_depth, config.rows_per_work_unit)
         h = C.c_void_p()
-        _lib.check(_lib.lib.flux_ctx_create(C.byref(self._desc.desc), C.byref(cfg), C.c_uint64(self.seed),
-                                            self.device, C.byref(h)))
+        self.set_share = (0, 1) if set_share is None else (int(set_share[0]), int(set_share[1]))
+        _lib.check(_lib.lib.flux_ctx_create_sets(C.byref(self._desc.desc), C.byref(cfg), C.c_uint64(self.seed),
+                                                 self.device, self.set_share[0], self.set_share[1], C.byref(h)))
         self._h = h
 
     # -- lifetime ------------------------------------------------------------
@@ -141,7 +145,7 @@ class Renderer:
         return dict(zip(names, [int(x) for x in buf]))
 
     def table(self, which: int) -> np.ndarray:
-        S = self.width
+        S = len(range(self.set_share[0], self.width, self.set_share[1]))  # the sets held, in slot order
         N = self.config.sample_root ** 2
         D = self.config.max_trace_depth
         shape = (S, N, 2) if which in (_lib.TABLE_PIXEL, _lib.TABLE_DISC) else (S, D, N, 3)

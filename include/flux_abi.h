@@ -143,6 +143,14 @@ int flux_device_count(void);
 int flux_ctx_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint64_t seed,
                     int device, flux_ctx **out);
 
+/* flux_ctx_create for ONE RANK of a set-sharded render (flux_render_sets_device with the same first_set / set_stride):
+ * the sample tables are generated and held only for the sets first_set + m*set_stride this rank owns -- 1/set_stride
+ * of MasterSampleSets::new's work and memory (sampling.rs:13-33).  A set's contents depend on (seed, set index) only,
+ * so they equal the full context's.  flux_render_rows* and flux_debug_shade need every set and are rejected on such a
+ * context; flux_ctx_copy_table returns the held sets in slot order.  first_set < set_stride. */
+int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint64_t seed, int device,
+                         uint64_t first_set, uint64_t set_stride, flux_ctx **out);
+
 /* Drops Scene + Camera (workers.rs:73-74). NULL is a no-op. */
 void flux_ctx_destroy(flux_ctx *ctx);
 

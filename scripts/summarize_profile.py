@@ -30,7 +30,9 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             name = row["Kernel_Name"]
             if "render_" not in name:
                 continue
-            counters[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            # pmc_sq2 repeats SQ_ACTIVE_INST_VALU next to SQ_THREAD_CYCLES_VALU: keep that pair apart (same pass)
+            cname = row["Counter_Name"] + ("@2" if d.endswith("pmc_sq2") and row["Counter_Name"] == "SQ_ACTIVE_INST_VALU" else "")
+            counters[name][cname].append(float(row["Counter_Value"]))
             for k in ("VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Workgroup_Size", "Grid_Size"):
                 meta[name][k] = float(row[k])
 
@@ -53,16 +55,22 @@ if calib:
     out["fetch_calibration"] = {k: {"fetch_size_bytes": v, "true_bytes": float(1 << 30),
                                     "true_over_reported": [float(1 << 30) / x if x else None for x in v]}
                                 for k, v in calib.items()}
-workload = None
+workload = scene = kname = spl = None
 for b in bench.values():
     workload = b.get("config", {}).get("workload", workload)
+    scene = b.get("config", {}).get("scene", scene)
+    kname = b.get("roofline", {}).get("kernel", kname)
+    spl = b.get("roofline", {}).get("samples_per_launch", spl)
 out["workload"] = workload
+out["scene"] = scene                 # bench.py matches a profile by scene + kernel and scales the counters per sample
+out["kernel"] = kname
+out["samples_per_launch"] = spl
 main = None
 for name, cs in counters.items():
     k = {c: sum(v) / len(v) for c, v in cs.items()}
     k.update(meta[name])
     out["kernels"][name] = k
-    if "<false>" in name or main is None:
+    if (kname and kname in name and "<true" not in name) or ("<false>" in name and not kname) or main is None:
         main = k
 if main and "FETCH_SIZE" in main and "WRITE_SIZE" in main:
     # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in units of 1024 B
@@ -82,5 +90,8 @@ if main and "SQ_ACTIVE_INST_VALU" in main and "SQ_BUSY_CYCLES" in main and main[
     out["valu_busy_frac"] = main["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * 1024.0)
     if "SQ_INSTS_VALU" in main and "SQ_WAVES" in main:
         out["valu_insts_per_launch"] = main["SQ_INSTS_VALU"]
+if main and "SQ_THREAD_CYCLES_VALU" in main and main.get("SQ_ACTIVE_INST_VALU@2"):
+    # lanes active per issued VALU instruction: thread-cycles / (64 lanes x instruction cycles), both from one pass
+    out["lanes_active_frac"] = main["SQ_THREAD_CYCLES_VALU"] / (64.0 * main["SQ_ACTIVE_INST_VALU@2"])
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "bench_lines"}, indent=1)[:3000])
