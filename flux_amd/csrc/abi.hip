@@ -485,6 +485,22 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
 
 static bool holds_all_sets(const flux_ctx *c) { return c->sets.stride == 1 && c->sets.first == 0; }
 
+// Dynamic + static LDS one block of `threads` threads needs: STRICT keeps the (f,s) recursion stack (4 doubles per level
+// per lane), mesh scenes the BVH traversal stack (one int per level per lane, none for brute force), the refill / split
+// kernels a few static words (per-wave totals).  64 KiB per block is the launch limit.
+static int check_lds_budget(const flux_ctx *ctx, size_t threads, const char *what) {
+    const size_t strict = ctx->math == FLUX_MATH_STRICT ? (size_t)ctx->D * 4 * threads * sizeof(double) : 0;
+    const bool bvh = ctx->d_tris != nullptr && ctx->traversal == FLUX_TRAVERSE_BVH;
+    const size_t stack = bvh ? (size_t)ctx->bvh.max_depth * threads * sizeof(int) : 0;
+    const size_t fixed = 512;
+    if (strict + stack + fixed > 64 * 1024)
+        return fail(FLUX_E_INVALID, "%s: %zu B of LDS per block (recursion stack %zu B for max_trace_depth %u%s, BVH stack %zu B "
+                    "for depth %llu) exceed the 64 KiB limit; use FLUX_MATH_FAST or a smaller max_trace_depth", what,
+                    strict + stack + fixed, strict, ctx->D, ctx->math == FLUX_MATH_STRICT ? " in FLUX_MATH_STRICT" : "", stack,
+                    (unsigned long long)ctx->bvh.max_depth);
+    return FLUX_OK;
+}
+
 int flux_ctx_set_kernel(flux_ctx *ctx, int variant) {
     if (!ctx) return fail(FLUX_E_INVALID, "null context");
     if (variant < FLUX_KERNEL_DEFAULT || variant > FLUX_KERNEL_SPLIT)
@@ -508,8 +524,7 @@ int flux_debug_shade(flux_ctx *ctx, uint64_t n, const double *rays, uint64_t dep
     if (!holds_all_sets(ctx)) return fail(FLUX_E_INVALID, "this context holds a share of the sample sets only (flux_ctx_create_sets)");
     if (depth < 1 || set_index >= ctx->S || sample_index >= ctx->N)
         return fail(FLUX_E_INVALID, "depth >= 1, set_index < %u and sample_index < %u required", ctx->S, ctx->N);
-    if (ctx->math == FLUX_MATH_STRICT && (size_t)ctx->D * 4 * 64 * sizeof(double) > 60 * 1024)
-        return fail(FLUX_E_INVALID, "max_trace_depth %u too deep for FLUX_MATH_STRICT (LDS recursion stack)", ctx->D);
+    if (int rc = check_lds_budget(ctx, 64, "flux_debug_shade")) return rc;
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(FLUX_E_DEVICE, "hipSetDevice(%d) failed", ctx->device);
     double *d_rays = nullptr, *d_rgb = nullptr, *d_t = nullptr;
@@ -604,14 +619,10 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
     p.num_rows = (int32_t)num_rows;
     p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
-    // STRICT keeps the (f,s) recursion stack in LDS: 4 doubles per level per lane, 64-thread blocks
     {
-        // STRICT keeps the (f,s) recursion stack in LDS: 4 doubles per level per lane; refill blocks hold up to 4 waves
-        size_t strict_threads = 64;  // 64 * K, K as in launch_render
-        while (strict_threads * 2 <= 64 * FLUX_MAX_WAVES_PER_PIXEL && strict_threads * 2 * 16 <= ctx->N) strict_threads *= 2;
-        if (ctx->math == FLUX_MATH_STRICT && (size_t)ctx->D * 4 * strict_threads * sizeof(double) > 60 * 1024)
-            return fail(FLUX_E_INVALID, "max_trace_depth %u needs %zu B of LDS per block in FLUX_MATH_STRICT (limit 60 KiB); "
-                        "use FLUX_MATH_FAST", ctx->D, (size_t)ctx->D * 4 * strict_threads * sizeof(double));
+        size_t threads = 64;  // 64 * K, K as in launch_render (refill / split blocks hold up to FLUX_MAX_WAVES_PER_PIXEL waves)
+        while (threads * 2 <= 64 * FLUX_MAX_WAVES_PER_PIXEL && threads * 2 * 16 <= ctx->N) threads *= 2;
+        if (int rc = check_lds_budget(ctx, threads, "flux_render_rows")) return rc;
     }
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
@@ -652,8 +663,7 @@ int flux_render_sets_device(flux_ctx *ctx, uint64_t first_set, uint64_t set_stri
     p.slot_stride = (int32_t)(set_stride / ctx->sets.stride);
     p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
-    if (ctx->math == FLUX_MATH_STRICT && (size_t)ctx->D * 4 * 64 * FLUX_MAX_WAVES_PER_PIXEL * sizeof(double) > 60 * 1024)
-        return fail(FLUX_E_INVALID, "max_trace_depth %u too deep for FLUX_MATH_STRICT (LDS recursion stack)", ctx->D);
+    if (int rc = check_lds_budget(ctx, 64 * FLUX_MAX_WAVES_PER_PIXEL, "flux_render_sets_device")) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
     HIP_TRY(hipEventRecord(ctx->ev1, stream));

@@ -239,7 +239,8 @@ void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &
         N.child0 = ~(int32_t)((0u << 3) | (uint32_t)tris.size());
         N.count0 = (int32_t)tris.size();
         Builder::empty_box(N.lo1, N.hi1);
-        N.child1 = ~0;  // empty leaf: never visited (inverted box), count 0
+        N.child1 = ~0;  // empty leaf, count 0.  Its inverted (+inf, -inf) box does NOT fail the symmetric min/max slab test
+                        // (tn = -inf, tf = +inf): the leaf is visited and its zero triangles are tested -- harmless
         N.count1 = 0;
         info.max_depth = 1;
         info.max_leaf = tris.size();

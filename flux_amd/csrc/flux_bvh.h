@@ -27,7 +27,7 @@ struct DevNode {
     float lo0[3], hi0[3];
     float lo1[3], hi1[3];
     int32_t child0, child1;
-    int32_t count0, count1;  // leaf triangle counts (0 for inner children; 0 + inverted box = empty)
+    int32_t count0, count1;  // leaf triangle counts (0 for inner children; a leaf reference with count 0 is an empty leaf)
 };
 static_assert(sizeof(DevNode) == 64, "DevNode layout");
 

@@ -33,8 +33,11 @@ __device__ __forceinline__ double frsqrt(double x) {
     return ffma(y0 * e, a, y0);
 }
 
-// sqrt(x), x >= 0 (x below 1e-300, including 0 and tiny negatives from rounding, gives ~0)
+// sqrt(x), x >= 0; sqrt(0) = 0 exactly.  The tiny NEGATIVES that 1 - c*c or a discriminant can round to are taken as 0:
+// unclamped, a negative x would run the iteration with g = x*y0 hugely negative and overflow to NaN, and one NaN sample
+// poisons a pixel's whole sum.  (The seed is taken of max(x, 1e-300) so that it stays finite.)
 __device__ __forceinline__ double fsqrt(double x) {
+    x = __builtin_fmax(x, 0.0);
     const double xs = __builtin_fmax(x, 1e-300);
     const double y0 = __builtin_amdgcn_rsq(xs);
     double g = x * y0;

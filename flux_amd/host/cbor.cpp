@@ -244,7 +244,9 @@ bool Decoder::read_string(int major, std::string &s) {
     if (info_ != 31) {
         const uint64_t n = val_;
         have_ = false;
-        if (n > (1ull << 31)) return fail("string too long");
+        // the head is peer-controlled: nothing is allocated beyond kMaxString (the protocol's strings are scene names and
+        // enum tags; a 9-byte head must not be able to demand gigabytes)
+        if (n > kMaxString) return fail("string too long");
         s.resize((size_t)n);
         if (n && !r_.read(&s[0], (size_t)n)) return fail("truncated string");
         return true;
@@ -259,7 +261,7 @@ bool Decoder::read_string(int major, std::string &s) {
         if (major_ != major || info_ == 31) return fail("bad chunk in indefinite string");
         const uint64_t n = val_;
         have_ = false;
-        if (n > (1ull << 31)) return fail("string too long");
+        if (n > kMaxString || s.size() + n > kMaxString) return fail("string too long");  // total over all chunks
         const size_t at = s.size();
         s.resize(at + (size_t)n);
         if (n && !r_.read(&s[at], (size_t)n)) return fail("truncated string");
@@ -292,6 +294,13 @@ bool Decoder::at_break() {
 }
 
 bool Decoder::skip() {
+    // nesting is peer-controlled: bounded like serde_cbor's recursion limit (128) instead of the C++ stack
+    struct Depth {
+        int &d;
+        explicit Depth(int &x) : d(x) { ++d; }
+        ~Depth() { --d; }
+    } guard(depth_);
+    if (depth_ > kMaxDepth) return fail("nesting too deep");
     const Type t = peek();
     uint64_t n;
     std::string s;

@@ -70,6 +70,8 @@ public:
     // Container headers: n = element (array) / pair (map) count, or kIndefinite; then read the elements and,
     // for kIndefinite, call at_break() before each element (it consumes the 0xff when it returns true).
     static constexpr uint64_t kIndefinite = ~0ull;
+    static constexpr uint64_t kMaxString = 1ull << 24;  // bytes of one (possibly chunked) string accepted from a peer
+    static constexpr int kMaxDepth = 128;               // container nesting accepted by skip() (serde_cbor's limit)
     bool read_array(uint64_t &n);
     bool read_map(uint64_t &n);
     bool at_break();
@@ -84,6 +86,7 @@ private:
     bool have_ = false, eof_ = false;
     int major_ = 0, info_ = 0;
     uint64_t val_ = 0;  // argument of the buffered head
+    int depth_ = 0;     // current nesting inside skip()
     std::string err_;
 };
 

@@ -178,6 +178,11 @@ int main(int argc, char **argv) {
     }
     image_builder.stop();
     for (auto &w : workers) w->stop();
+    if (GpuWorker::failures() > 0) {
+        std::fprintf(stderr, "error: %d job(s) / work unit(s) were abandoned by a GPU worker; the image is incomplete\n",
+                     GpuWorker::failures());
+        rc = 1;
+    }
     if (rc == 0 && !image_builder.written_path.empty()) {
         const double samples = (double)s.output_settings.image_width * s.output_settings.image_height *
                                config.sample_root * config.sample_root;

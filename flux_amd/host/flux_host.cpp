@@ -226,6 +226,9 @@ void GpuWorker::stop() {  // workers.rs:95-98: send(None), join
     if (thread_.joinable()) thread_.join();
 }
 
+std::atomic<int> GpuWorker::worker_failures_{0};
+int GpuWorker::failures() { return worker_failures_.load(); }
+
 void GpuWorker::run() {
     // 'main: while let Ok(Some((job, recv_unit, send_result, wg))) = r.recv()   (workers.rs:43)
     for (;;) {
@@ -240,20 +243,39 @@ void GpuWorker::run() {
         if (flux_ctx_create(&abi.desc, &cfg, seed_, device_, &ctx) != FLUX_OK) {
             // the reference would panic in the worker thread (workers.rs:78); report and give the job up
             std::fprintf(stderr, "GpuWorker(device %d): %s\n", device_, flux_last_error());
+            worker_failures_.fetch_add(1);
             req.wg->done();
             continue;
         }
         const size_t w = req.job->scene_data.output_settings.image_width;
+        const size_t h = req.job->scene_data.output_settings.image_height;
         std::vector<double> buf;
-        bool abandoned = false;
         // while let Ok(unit) = recv_unit.recv()   (workers.rs:56)
         while (auto unit = req.recv_unit->recv()) {
+            // A unit may come straight off a socket (flux_node): validate before sizing anything.  An inverted range is
+            // what the reference renders as NO rows (`row_start..=row_end` is empty, trace.rs:62); rows past the image
+            // would make its ImageBuilder index out of bounds (manager.rs:322-324) -- here the unit is refused.
+            if (unit->row_end < unit->row_start) {
+                RenderEvent ev;
+                ev.kind = RenderEvent::RowsReady;
+                ev.result.work_unit = *unit;
+                req.send_result->send(std::move(ev));
+                continue;
+            }
+            if (unit->row_end >= h) {
+                std::fprintf(stderr, "GpuWorker(device %d): work unit rows [%zu,%zu] outside image height %zu\n", device_,
+                             (size_t)unit->row_start, (size_t)unit->row_end, h);
+                worker_failures_.fetch_add(1);
+                break;
+            }
             const size_t nrows = unit->row_end - unit->row_start + 1;
             buf.resize(nrows * w * 3);
             // camera.render(&scene, unit)   (workers.rs:60)
             if (flux_render_rows(ctx, unit->row_start, unit->row_end, buf.data()) != FLUX_OK) {
+                // the reference would panic here and take the process down (workers.rs:78); a C++ worker thread records
+                // the failure so that the front-end exits non-zero instead of reporting a frame with missing rows
                 std::fprintf(stderr, "GpuWorker(device %d): %s\n", device_, flux_last_error());
-                abandoned = true;
+                worker_failures_.fetch_add(1);
                 break;
             }
             RenderEvent ev;
@@ -268,7 +290,6 @@ void GpuWorker::run() {
             }
             req.send_result->send(std::move(ev));
         }
-        (void)abandoned;
         flux_ctx_destroy(ctx);
         req.wg->done();  // drop(wg)   (workers.rs:74)
     }

@@ -11,6 +11,7 @@
 // The reference is Rust; this image has no Rust toolchain, so the mirror is C++ (std::thread and a
 // small channel instead of crossbeam).  All rendering goes through include/flux_abi.h.
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -177,8 +178,12 @@ public:
     WorkerHandle handle() const override { return WorkerHandle(sender_); }
     void stop() override;
     WorkerInfo info() const override { return WorkerInfo{1}; }
+    // jobs / work units any GpuWorker of this process had to give up (context creation or a render call failed, or a
+    // unit was out of range): the reference panics there (workers.rs:78); the front-ends exit non-zero when this is > 0
+    static int failures();
 private:
     void run();
+    static std::atomic<int> worker_failures_;
     int device_;
     uint64_t seed_;
     std::shared_ptr<Channel<std::optional<WorkerRequest>>> sender_;

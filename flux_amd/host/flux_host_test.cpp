@@ -433,6 +433,29 @@ int main(int argc, char **argv) {
             CHECK(d2.skip() && d2.skip() && d2.skip());          // whole items of every container flavour
             CHECK(!d2.skip() && d2.failed());                    // truncated head
         }
+        {   // hostile input is a decode error, not an allocation or a stack overflow
+            std::string huge = unhex("7b00000000ffffffff");      // text string head claiming 4 GiB - 1, no payload
+            cbor::StringReader r(huge);
+            cbor::Decoder d(r);
+            std::string st;
+            CHECK(!d.read_text(st) && d.failed() && st.capacity() < (1u << 20));
+            std::string chunked = "\x5f";                       // indefinite byte string of 17 MiB in 1 MiB chunks
+            for (int k = 0; k < 17; k++) chunked += unhex("5a00100000") + std::string(1u << 20, 'x');
+            chunked += "\xff";
+            cbor::StringReader rc(chunked);
+            cbor::Decoder dc(rc);
+            CHECK(!dc.read_bytes(st) && dc.failed());            // total capped at Decoder::kMaxString (16 MiB)
+            std::string deep(100000, '\x81');                    // 100000 nested one-element arrays
+            deep += "\x01";
+            cbor::StringReader rd(deep);
+            cbor::Decoder dd(rd);
+            CHECK(!dd.skip() && dd.failed());
+            std::string ok(100, '\x81');
+            ok += "\x01";
+            cbor::StringReader ro(ok);
+            cbor::Decoder dok(ro);
+            CHECK(dok.skip() && !dok.failed());                  // 100 levels: inside serde_cbor's limit of 128
+        }
         std::puts("ok cbor");
     }
     {

@@ -1,4 +1,5 @@
 // flux_net.cpp -- see flux_net.hpp.
+#include <algorithm>
 #include "flux_net.hpp"
 
 #include <arpa/inet.h>
@@ -542,7 +543,7 @@ bool decode_event(Decoder &d, RenderEvent &ev) {
                         uint64_t m;
                         if (d.failed() || !d.read_array(m)) return false;
                         std::vector<Color> row;
-                        if (m != Decoder::kIndefinite) row.reserve((size_t)m);
+                        if (m != Decoder::kIndefinite) row.reserve((size_t)std::min<uint64_t>(m, 1u << 16));  // the count is peer-controlled
                         for (uint64_t c = 0; m == Decoder::kIndefinite ? !d.at_break() : c < m; c++) {
                             Color col;
                             if (d.failed() || !dec_color(d, col)) return false;

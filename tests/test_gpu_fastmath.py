@@ -32,6 +32,9 @@ def test_rsqrt_sqrt_div(flux, rng):
     assert ulp_err(flux.debug_fastmath(RSQRT, x), want).max() <= 2.0
     assert ulp_err(flux.debug_fastmath(SQRT, x), np.sqrt(x)).max() <= 1.0
     assert np.array_equal(flux.debug_fastmath(SQRT, np.array([0.0, 1.0, 4.0, 2.25])), [0.0, 1.0, 2.0, 1.5])
+    # tiny negatives (1 - c*c or a discriminant rounded below zero) are 0, never NaN
+    neg = -np.concatenate([10.0 ** rng.uniform(-320, -10, 2000), [1e-16, 2.2e-16, 5e-324, 0.0]])
+    assert np.array_equal(flux.debug_fastmath(SQRT, neg), np.zeros_like(neg))
     a = rng.uniform(-10, 10, 40000)
     b = np.concatenate([rng.uniform(0.5, 4.0, 20000), 10.0 ** rng.uniform(-20, 20, 20000)])
     assert ulp_err(flux.debug_fastmath(DIV, a, b), a / b).max() <= 1.0

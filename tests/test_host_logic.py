@@ -52,3 +52,25 @@ def test_no_gpu_means_loud_failure(flux, demo1):
         pytest.skip("GPU present")
     with pytest.raises(flux.FluxError, match="no HIP device"):
         flux.Renderer(demo1, flux.JobConfiguration(1, 5, 50))
+
+
+def test_bench_self_launches_ranks_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus N` from a bare shell (what the driver runs) starts N ranks itself -- fresh interpreters
+    under torch.distributed.run, spawned before anything touches a GPU -- and the whole launch exits non-zero when a rank
+    fails.  Here (no GPU) every rank refuses to run: there is no CPU fallback to report a number from."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    import flux_amd
+    if flux_amd._lib.lib.flux_device_count() >= 2:
+        assert p.returncode == 0 and '"n_gpus": 2' in p.stdout, p.stderr[-2000:]
+    else:
+        assert p.returncode != 0
+        assert p.stdout.strip() == ""                                  # no bench line without the GPUs
+        assert p.stderr.count("needs a GPU") == 2 or "invalid device ordinal" in p.stderr or "out of range" in p.stderr
