@@ -73,6 +73,7 @@ struct flux_ctx {
     // extension: triangle meshes
     flux::DevTri *d_tris = nullptr;
     flux::DevNode *d_nodes = nullptr;
+    flux::DevNodeQ *d_nodesq = nullptr;
     flux::BvhInfo bvh{};
     int traversal = FLUX_TRAVERSE_BVH;
     int variant = FLUX_KERNEL_DEFAULT;
@@ -115,6 +116,7 @@ static void free_ctx(flux_ctx *c) {
     (void)hipFree(c->d_stats);
     (void)hipFree(c->d_tris);
     (void)hipFree(c->d_nodes);
+    (void)hipFree(c->d_nodesq);
     (void)hipFree(c->d_out);
     delete c;
 }
@@ -358,7 +360,9 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
             tris.push_back(t);
         }
     }
+    std::vector<flux::DevNodeQ> nodesq;
     flux::build_bvh(tris, nodes, c->bvh);
+    flux::quantize_bvh(nodes, nodesq, c->bvh);
     if (c->bvh.max_depth > (uint64_t)flux::kBvhMaxDepth) {
         int code = fail(FLUX_E_INVALID, "BVH depth %llu exceeds %d (degenerate mesh)",
                         (unsigned long long)c->bvh.max_depth, flux::kBvhMaxDepth);
@@ -431,6 +435,8 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         alloc((void **)&c->d_nodes, nodes.size() * sizeof(flux::DevNode));
         if (e == hipSuccess) e = hipMemcpy(c->d_tris, tris.data(), tris.size() * sizeof(flux::DevTri), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(c->d_nodes, nodes.data(), nodes.size() * sizeof(flux::DevNode), hipMemcpyHostToDevice);
+        alloc((void **)&c->d_nodesq, nodesq.size() * sizeof(flux::DevNodeQ));
+        if (e == hipSuccess) e = hipMemcpy(c->d_nodesq, nodesq.data(), nodesq.size() * sizeof(flux::DevNodeQ), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMemcpy(c->d_shapes, shapes.data(), shapes.size() * sizeof(flux::DevShape), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_mats, mats.data(), mats.size() * sizeof(flux::DevMaterial), hipMemcpyHostToDevice);
@@ -464,6 +470,11 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.nodes = c->d_nodes;
     rp.n_tris = (int32_t)tris.size();
     rp.bvh_stack = (int32_t)c->bvh.max_depth;
+    rp.nodesq = c->d_nodesq;
+    for (int a = 0; a < 3; a++) {
+        rp.bvh_qmin[a] = c->bvh.qmin[a];
+        rp.bvh_qstep[a] = c->bvh.qstep[a];
+    }
     rp.fsph = reinterpret_cast<const flux::DevScanSphere *>(c->d_fscene);
     rp.fpln = reinterpret_cast<const flux::DevScanPlane *>(c->d_fscene + fs_sph_bytes);
     rp.frec = reinterpret_cast<const flux::DevHitRec *>(c->d_fscene + fs_sph_bytes + fs_pln_bytes);

@@ -279,4 +279,57 @@ void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &
                         std::chrono::steady_clock::now() - t0).count();
 }
 
+void quantize_bvh(const std::vector<DevNode> &nodes, std::vector<DevNodeQ> &out, BvhInfo &info) {
+    out.clear();
+    if (nodes.empty()) return;
+    // grid over all FINITE box corners (the one-leaf tree's empty slot is an inverted infinite box)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto grow = [&](const float *l, const float *h) {
+        for (int a = 0; a < 3; a++) {
+            if (std::isfinite(l[a])) lo[a] = std::min(lo[a], l[a]);
+            if (std::isfinite(h[a])) hi[a] = std::max(hi[a], h[a]);
+        }
+    };
+    for (const DevNode &N : nodes) {
+        grow(N.lo0, N.hi0);
+        grow(N.lo1, N.hi1);
+    }
+    // grid: value(q) = qmin + q * qstep with qmin ONE QUANTUM BELOW the lowest corner, so that q = 1 is the lowest corner,
+    // the highest is at most q = 65534, and 0 / 65535 remain for the extra quantum every box is widened by
+    for (int a = 0; a < 3; a++) {
+        if (!(hi[a] >= lo[a])) lo[a] = hi[a] = 0.0f;
+        const double ext = (double)hi[a] - (double)lo[a];
+        float st = (float)(ext / 65533.0 * (1.0 + 1e-6));
+        if (!(st > 0.0f)) st = 1e-30f;
+        while ((double)st * 65533.0 < ext) st = std::nextafterf(st, INFINITY);
+        info.qstep[a] = st;
+        float org = (float)((double)lo[a] - (double)st);
+        while ((double)org + (double)st > (double)lo[a]) org = std::nextafterf(org, -INFINITY);
+        info.qmin[a] = org;
+    }
+    auto qlo = [&](float v, int a) -> uint16_t {  // a grid point at least one quantum below v
+        if (!std::isfinite(v)) return v > 0 ? 65535 : 0;
+        double q = std::floor(((double)v - (double)info.qmin[a]) / (double)info.qstep[a]) - 1.0;
+        return (uint16_t)std::min(std::max(q, 0.0), 65535.0);
+    };
+    auto qhi = [&](float v, int a) -> uint16_t {  // a grid point at least one quantum above v
+        if (!std::isfinite(v)) return v > 0 ? 65535 : 0;
+        double q = std::ceil(((double)v - (double)info.qmin[a]) / (double)info.qstep[a]) + 1.0;
+        return (uint16_t)std::min(std::max(q, 0.0), 65535.0);
+    };
+    out.resize(nodes.size());
+    for (size_t k = 0; k < nodes.size(); k++) {
+        const DevNode &N = nodes[k];
+        DevNodeQ &Q = out[k];
+        for (int a = 0; a < 3; a++) {
+            Q.lo0[a] = qlo(N.lo0[a], a);
+            Q.hi0[a] = qhi(N.hi0[a], a);
+            Q.lo1[a] = qlo(N.lo1[a], a);
+            Q.hi1[a] = qhi(N.hi1[a], a);
+        }
+        Q.child0 = N.child0;
+        Q.child1 = N.child1;
+    }
+}
+
 }  // namespace flux

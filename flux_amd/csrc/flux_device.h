@@ -156,6 +156,8 @@ struct RenderParams {
     // extension: triangle meshes (0 / nullptr for reference scenes)
     const DevTri *tris;    // leaf order
     const DevNode *nodes;  // node 0 = root
+    const DevNodeQ *nodesq;  // the same nodes, 32 B each, boxes on a 16-bit grid (FAST traversal state machine)
+    float bvh_qmin[3], bvh_qstep[3];  // that grid: coordinate = qmin + q * qstep
     int32_t n_tris;
     int32_t bvh_stack;     // per-lane traversal stack entries (= BVH max depth); 0 = brute force
     // FAST path scene (same shapes as `shapes`/`mats`)
