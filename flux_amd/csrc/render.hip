@@ -45,10 +45,17 @@
 #define FLUX_WPE_BVH 5            // waves/SIMD of the BVH traversal kernel
 #endif
 #ifndef FLUX_BVH_REFILL_AT
-#define FLUX_BVH_REFILL_AT 32     // lanes that must be waiting for shading before the wave leaves traversal
+#define FLUX_BVH_REFILL_AT 40     // lanes that must be waiting for shading before the wave leaves traversal (swept 16..64 with the leaf vote)
 #endif
 #ifndef FLUX_WPE_SPLIT
 #define FLUX_WPE_SPLIT 4          // waves/SIMD of the split kernel (two path states live in phase A)
+#endif
+#ifndef FLUX_BVH_LEAF_VOTE
+#define FLUX_BVH_LEAF_VOTE 1      // leave the inner-node loop once the lanes holding a leaf outweigh the descending ones
+#endif
+#ifndef FLUX_BVH_LEAF_NUM
+#define FLUX_BVH_LEAF_NUM 1       // ... i.e. when n_leaf * NUM > n_inner * DEN
+#define FLUX_BVH_LEAF_DEN 1
 #endif
 #ifndef FLUX_WAVES_PER_EU_FAST
 #define FLUX_WAVES_PER_EU_FAST 5
