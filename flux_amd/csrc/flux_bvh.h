@@ -12,9 +12,9 @@ struct DevTri {
     double v0x, v0y, v0z;
     double e1x, e1y, e1z;  // v1 - v0
     double e2x, e2y, e2z;  // v2 - v0
-    double nx, ny, nz;     // normalize(e1 x e2), never flipped
-    int32_t id;            // index in hit order: num_shapes + position in the input meshes
-    int32_t mat;           // index into the material array
+    int32_t id;            // index in hit order: num_shapes + position in the input meshes.  Right behind the edges: the
+    int32_t mat;           // intersection test then reads bytes 0..79 = five 16-B gathers.  mat: index into the materials
+    double nx, ny, nz;     // normalize(e1 x e2), never flipped (read when shading only)
     double pad[3];
 };
 static_assert(sizeof(DevTri) == 128, "DevTri layout");
