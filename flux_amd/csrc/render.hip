@@ -18,8 +18,14 @@
 //  * the reference's recursion  L = (f1 (*) ((f2 (*) (...)) * s2)) * s1  is run iteratively -- STRICT pushes
 //    (f, s = n.wi/pdf) on a per-lane LDS stack and folds it from the deepest bounce outward (the reference's
 //    multiplication order), FAST multiplies a register throughput;
-//  * REFILL variant: a lane whose path ended immediately takes the slice's next unstarted sample (ballot +
-//    mbcnt prefix), so lanes stay busy although path lengths differ (1..D segments);
+//  * SPLIT kernel (FAST, analytic scenes, the default from 256 spp): PRIMARY segments -- all lanes of a wave sample
+//    one pixel, so their rays are coherent -- are traced 64 at a time against the pixel's own candidate spheres
+//    (a wave-uniform mask, scalar operands, uniform control flow) and shaded together; the continuing paths go
+//    through a 64-entry LDS queue to the SECONDARY loop, where a lane whose path ended pops the next queued path
+//    (ballot + mbcnt prefix), so lanes stay busy although path lengths differ (1..D segments);
+//  * REFILL kernel (STRICT; 64..255 spp): the same refill discipline with primaries and secondaries mixed in one loop;
+//    STATIC kernel (< 64 spp): lane l traces samples l, l+64, ...;
+//  * BVH kernel (FAST mesh scenes): persistent lanes with a per-lane traversal state machine over 32-B quantised nodes;
 //  * per-lane partial sums are combined in lane order, wave totals in wave order (a fixed tree => the image is
 //    bit-reproducible run to run and independent of how the frame is split), then * 1/n^2, max_to_one, and the
 //    3 doubles are written once.  No atomics.
