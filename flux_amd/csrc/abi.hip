@@ -488,6 +488,10 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.out_by_set = 0;
     rp.slot_first = 0;
     rp.slot_stride = 1;
+    rp.glossy_long = 0;
+    for (const flux::DevHitRec &hr : frec_p)
+        if (!hr.unit_normal) rp.glossy_long = 1;
+    rp.pad_gl = 0;
     rp.n_sph = (int32_t)fsph.size();
     rp.n_pln = (int32_t)fpln.size();
     *out = c;
@@ -547,6 +551,7 @@ int flux_debug_shade(flux_ctx *ctx, uint64_t n, const double *rays, uint64_t dep
     if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice);
     flux::RenderParams p = ctx->rp;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
+    p.glossy_long = 1;  // caller-supplied directions need not be unit vectors
     if (e == hipSuccess)
         e = flux::launch_shade_rays(p, ctx->math, d_rays, (int)n, (int)depth, (uint32_t)set_index, (uint32_t)sample_index,
                                     d_rgb, d_hit, d_t, nullptr);

@@ -174,6 +174,9 @@ struct RenderParams {
     // table slot of set set_first + m*set_stride: slot_first + m*slot_stride (equal to the set index itself unless the
     // context holds only a subset of the sets, flux_ctx_create_sets).  The kernels address pix/disc/hemi/gloss by slot.
     int32_t slot_first, slot_stride;
+    // FAST: 1 = the scene has a plane whose stored normal is not a unit vector, so a reflected direction may not be one
+    // and the Phong lobe may under/overflow: glossy bounces then use the reference's long-form weight (render_body.inc)
+    int32_t glossy_long, pad_gl;
 };
 
 }  // namespace flux

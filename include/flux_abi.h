@@ -198,9 +198,10 @@ int flux_ctx_set_kernel(flux_ctx *ctx, int variant);
  * north-star tolerance (1e-4 per channel):
  *   FLUX_MATH_FAST (default): the reference's estimator evaluated for the machine -- FMA contraction,
  *       division/sqrt/pow/sincos from flux_math.h (<= ~2 ulp), no BoundingBox::hit pre-test (implied by
- *       the sphere quadratic), path throughput multiplied front to back, bounce weights in closed form (where the
- *       reference's long form under/overflows -- only possible with non-unit plane normals -- it yields NaN and
- *       FAST the analytic value);
+ *       the sphere quadratic), path throughput multiplied front to back, bounce weights in closed form.  The glossy
+ *       closed form (cs ks: the Phong lobe cancels) is used only where the lobe cannot under/overflow, i.e. in scenes
+ *       whose plane normals are unit vectors; a scene with a non-unit plane normal gets the reference's long form for
+ *       every glossy bounce, so the NaN pixels such a scene has in the reference appear here too;
  *   FLUX_MATH_STRICT: the reference's operation order, no contraction, IEEE division/sqrt, OCML
  *       pow/sincos, BoundingBox::hit before every sphere, (f,s) stack folded deepest bounce first. */
 #define FLUX_MATH_FAST 0

@@ -89,16 +89,17 @@ def test_random_scenes_against_the_oracle(flux, oracle_mod, demo1, chunk):
                     # Where the reference's own arithmetic breaks down -- a Phong lobe (r.wi)^e that under- or
                     # overflows, which needs a non-unit plane normal (for unit normals lobe >= 1 - y) -- its long
                     # form f (n.wi)/pdf yields NaN (0 * inf) or a value degraded by subnormal rounding.  STRICT
-                    # must reproduce exactly that, NaN positions included; FAST's closed-form weight returns the
-                    # finite analytic value instead, so its IMAGE is compared only on scenes where the reference
-                    # produced no NaN at all (its decisions -- the statistics above -- are compared always).
-                    if math == flux.MATH_STRICT:
-                        assert np.array_equal(np.isfinite(got), finite), tag
+                    # reproduces exactly that; FAST uses the closed-form weight only for unit reflected directions
+                    # and the long form otherwise (FLUX_GLOSSY_LONG_FORM), so its NaN pixels are the reference's too.
+                    assert np.array_equal(np.isfinite(got), finite), tag          # NaN pixels: the reference's, in BOTH modes
+                    if math == flux.MATH_STRICT or finite.all():
                         assert max_abs_diff(got[finite], want[finite]) < 1e-4 if finite.any() else True, tag
-                    elif finite.all():
-                        assert max_abs_diff(got, want) < 1e-4, tag
                     else:
-                        assert np.isfinite(got).all(), tag
+                        # FAST next to NaN pixels: the same long form (r.wi)^e, but a lobe in the subnormal range is
+                        # "degraded" differently by its own arithmetic (front-to-back throughput vs the reference's
+                        # recursion order), so finite neighbours are compared loosely
+                        bad = np.abs(got[finite] - want[finite]) > 1e-4
+                        assert not finite.any() or bad.mean() < 0.02, (tag, float(bad.mean()))
 
 
 @pytest.mark.parametrize("chunk", range(4))
