@@ -337,3 +337,28 @@ def test_set_sharded_render_equals_full_frame(flux, demo2, math, world):
         r.set_kernel(flux.KERNEL_STATIC)
         with pytest.raises(flux.FluxError):
             r.render_sets_device(0, 1, 40, s0.render_buf.data_ptr())   # needs the refill kernel
+
+
+@pytest.mark.parametrize("lens,focal,pixel", [(5.0, 3.0, 6.0), (0.9, 1.0, 40.0), (0.0, 10.0, 400.0)])
+def test_split_kernel_with_extreme_cameras(flux, oracle_mod, demo2, lens, focal, pixel):
+    """The split kernel's per-pixel candidate mask (pixel_sphere_mask) must stay a superset of what any primary ray of
+    the pixel can hit, also for ray bundles that are anything but narrow: a lens wider than the focal distance (the
+    bundle's cone opens beyond 45 degrees), and pixels whose footprint spans the whole scene.  Path statistics equal to the
+    oracle's mean no hit was missed."""
+    import copy
+    sd = copy.deepcopy(small_scene(demo2, 24, 18))
+    sd.camera_data.lens_radius = lens
+    sd.camera_data.focal_distance = focal
+    sd.output_settings.pixel_size = pixel
+    cfg = flux.JobConfiguration(16, 5, 50)   # 256 spp: the split kernel's range
+    o = oracle_mod.Oracle(sd, cfg, seed=9)
+    o.stats(reset=True)
+    want = o.render_frame(threads=8)
+    with flux.Renderer(sd, cfg, seed=9) as r:
+        r.set_kernel(flux.KERNEL_SPLIT)
+        r.enable_stats(True)
+        r.stats(reset=True)
+        got = r.render_frame()
+        st = r.stats()
+    assert {k: st[k] for k in o.stats()} == o.stats()
+    assert max_abs_diff(got, want) < TOL_IMAGE
