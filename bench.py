@@ -153,11 +153,19 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the renderer has no CPU fallback)")
+    # Rehearsal of the N > 1 path on a one-GPU box (FLUX_BENCH_REHEARSE=1): every rank on device 0, the gather over gloo
+    # through the host -- everything but RCCL itself; never the measured configuration (the line says so)
+    rehearse = os.environ.get("FLUX_BENCH_REHEARSE") == "1" and world > 1
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if a.scene.startswith("hf:"):  # BASELINE config 5: procedural height field, e.g. hf:1000x500 = 1M triangles
         from flux_amd.procedural import heightfield_scene
@@ -294,7 +302,8 @@ def main():
                        "parallelism": (f"pixel-set tiles (one pixel per row per owned sample set; each rank holds only its "
                                        f"sets' tables) over {world} GPU(s), 1 all_gather" if use_sets else
                                        f"row-interleaved image tiles over {world} GPU(s), 1 all_gather"),
-                       "finite": finite},
+                       "finite": finite, **({"rehearsal": "all ranks on ONE GPU, gather over gloo: not a measurement"}
+                                            if rehearse else {})},
             "step_breakdown_ms": {"render": round(kernel_ms_max, 3), "all_gather": round(gather_ms_max, 3),
                                   "reassembly": round(assemble_ms_max, 3),
                                   "note": "HIP events on the launch stream, mean over steps, max over ranks"},

@@ -17,6 +17,16 @@ import torch
 import torch.distributed as dist
 
 
+def _all_gather(gathered: torch.Tensor, local: torch.Tensor, group=None):
+    """all_gather_into_tensor; over gloo (tests, rehearsals: several ranks on one GPU) device tensors go through the host."""
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(gathered.shape, dtype=gathered.dtype)
+        dist.all_gather_into_tensor(host.view(-1), local.detach().cpu().view(-1), group=group)
+        gathered.copy_(host)
+    else:
+        dist.all_gather_into_tensor(gathered.view(-1), local.view(-1), group=group)
+
+
 def rank_rows(height: int, rank: int, world: int) -> Tuple[int, int, int]:
     """(first_row, row_stride, num_rows) of `rank`'s share of an image of `height` rows."""
     if not (0 <= rank < world):
@@ -51,7 +61,7 @@ class FrameSharder:
     def collect(self):
         """The ONE collective of a frame: all_gather of every rank's row buffer (RCCL over xGMI on GPUs)."""
         if self.world > 1:
-            dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
+            _all_gather(self.gathered, self.local, self.group)
 
     def assemble(self) -> torch.Tensor:
         """The gathered buffers in image order: [H][W][3] (a view, valid on every rank)."""
@@ -103,7 +113,7 @@ class SetSharder:
         if self.local is not self.render_buf:
             self.local[:, : self.count] = self.render_buf
         if self.world > 1:
-            dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
+            _all_gather(self.gathered, self.local, self.group)
 
     def assemble(self) -> torch.Tensor:
         """One indexed read with the row permutation: pixel (r, c) uses set s = rowperm[r][c], rendered by rank s % G
