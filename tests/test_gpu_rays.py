@@ -138,3 +138,39 @@ def test_random_rays_with_triangles(flux, oracle_mod, demo2, math):
     dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
     hit, _, _ = _check(flux, oracle_mod, sd, origins, dirs, math, rgb_tol=1e-8)
     assert (hit >= len(sd.shapes) - 1).sum() > 100  # a good share of first hits are triangles
+
+
+@pytest.mark.parametrize("math", MODES)
+def test_grazing_rays_through_the_f32_filter(flux, oracle_mod, demo2, math):
+    """FAST's candidate filter runs in packed f32 with a conservative bias: it may let extra spheres
+    through but must never drop one the exact f64 test would hit.  Rays aimed past every sphere of demo2 with an impact
+    parameter r (1 -/+ eps) -- from near and far origins, towards and away from the sphere, from inside the environment
+    sphere's shell -- must hit exactly what the oracle says (first-hit id, distance).  eps runs from 1e-3 down to 1e-15
+    in STRICT (the oracle's own formula: decisions agree to the last bit) and down to 1e-11 in FAST, whose half-b
+    discriminant along the unit direction rounds differently from b^2 - 4ac once the discriminant 2 r^2 eps is within
+    a few ulp of |o - p|^2 (observed: the two disagree only at eps <= 1e-14)."""
+    from flux_amd.scene import SphereData
+    rng = np.random.default_rng(11)
+    origins, dirs = [], []
+    for s in demo2.shapes:
+        if not isinstance(s, SphereData):
+            continue
+        c, r = np.array(s.center, dtype=np.float64), float(s.radius)
+        for eps in 10.0 ** -np.arange(3, 16 if math == "strict" else 12):
+            for sign in (-1.0, 1.0):
+                for dist in (1.5, 7.0, 40.0):
+                    u = rng.normal(size=3)
+                    u /= np.linalg.norm(u)
+                    v = np.cross(u, rng.normal(size=3))
+                    v /= np.linalg.norm(v)
+                    o = c - u * (r + dist) + v * r * (1.0 + sign * eps)   # passes the centre at distance r (1 +/- eps)
+                    if s.invert and np.linalg.norm(o) >= 99.0:
+                        o = c + v * r * (1.0 - eps)                      # the environment sphere: start just inside its shell
+                    origins.append(o)
+                    dirs.append(u)
+                    origins.append(o)
+                    dirs.append(-u)                                      # and the same line the other way round
+    origins, dirs = np.array(origins), np.array(dirs)
+    sd = copy.deepcopy(small_scene(demo2, 16, 12))
+    hit, _, _ = _check(flux, oracle_mod, sd, origins, dirs, math, depth=5, rgb_tol=1e-7)
+    assert len(set(hit.tolist())) >= 10       # the rays really do reach most of the scene's shapes
