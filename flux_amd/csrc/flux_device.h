@@ -28,6 +28,11 @@
 #define FLUX_FILTER32 1
 #endif
 
+// split kernel, phase A: 1 = take the (normalised) primary direction as the unit direction of the sphere quadratic
+#ifndef FLUX_PRIMARY_UNIT
+#define FLUX_PRIMARY_UNIT 1
+#endif
+
 // refill kernel: most waves that share one pixel's samples (launch_render picks K <= this, a power of two)
 #ifndef FLUX_MAX_WAVES_PER_PIXEL
 #define FLUX_MAX_WAVES_PER_PIXEL 4
