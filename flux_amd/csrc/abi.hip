@@ -637,7 +637,7 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
     {
         size_t threads = 64;  // 64 * K, K as in launch_render (refill / split blocks hold up to FLUX_MAX_WAVES_PER_PIXEL waves)
-        while (threads * 2 <= 64 * FLUX_MAX_WAVES_PER_PIXEL && threads * 2 * 16 <= ctx->N) threads *= 2;
+        while (threads * 2 <= 64 * FLUX_MAX_WAVES_PER_PIXEL && threads * 2 * (FLUX_MIN_SAMPLES_PER_WAVE / 64) <= ctx->N) threads *= 2;
         if (int rc = check_lds_budget(ctx, threads, "flux_render_rows")) return rc;
     }
     HIP_TRY(hipEventRecord(ctx->ev0, stream));

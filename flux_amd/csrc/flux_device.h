@@ -37,6 +37,12 @@
 #ifndef FLUX_MAX_WAVES_PER_PIXEL
 #define FLUX_MAX_WAVES_PER_PIXEL 4
 #endif
+// ... each wave of a pixel's block gets at least this many samples (a multiple of 64): a wave's slice ends with a
+// drain of a few passes at falling occupancy, so short slices cost throughput; long ones cost balance at the end of a
+// launch.  K depends on the sample count only, never on how a frame is split.
+#ifndef FLUX_MIN_SAMPLES_PER_WAVE
+#define FLUX_MIN_SAMPLES_PER_WAVE 4096
+#endif
 
 namespace flux {
 
