@@ -226,6 +226,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max, kernel_ms_max, gather_ms_max, assemble_ms_max = [float(x) for x in t]
 
+    # what HBM delivers on THIS device ("report against both" the 8 TB/s spec and a measured copy): a 1 GiB
+    # device-to-device copy, read + write bytes, best of 5 (untimed extra)
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e30
+        for _ in range(5):
+            e0.record()
+            dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        copy_gbs = 2.0 * src.numel() * 4 / (best * 1e-3) / 1e9
+        del src, dst
+
     # exact path statistics of THIS rank's share (untimed extra pass) -> algorithmic bytes
     r.enable_stats(True)
     r.stats(reset=True)
@@ -310,6 +328,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "basis": basis,
+                         "measured_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
+                         "frac_of_measured_copy": (None if achieved is None or not copy_gbs else
+                                                   round(achieved / copy_gbs, 6)),
                          "algorithmic_gbs": round(alg_gbs, 3),
                          "traffic_gbs": None if traffic_gbs is None else round(traffic_gbs, 3),
                          "profile": prof["file"] if prof else None,
