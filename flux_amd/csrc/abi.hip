@@ -307,6 +307,17 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         const flux::DevScanSphere &sp = fsph[k];
         const double pp = sp.px * sp.px + sp.py * sp.py + sp.pz * sp.pz;
         if (!(pp < 1e30) || !(sp.rr < 1e30)) filter32_ok = false;
+    }
+    // `invert` spheres (environments: nearly every ray is inside and hits them) are tested for all lanes together with
+    // scalar operands instead of through every lane's candidate list (render_body.inc scan_shapes_fast): up to two,
+    // given a filter record that never passes (c = 3e38: "entirely behind the origin" or dq < 0)
+    int n_uni = 0, uni_idx[2] = {0, 0};
+    if (FLUX_FILTER32 && filter32_ok)
+        for (size_t k = 0; k < fsph.size() && n_uni < FLUX_UNI_SPHERES; k++)
+            if (frec_s[k].inv_rad < 0.0) uni_idx[n_uni++] = (int)k;
+    for (size_t k = 0; k < fsph.size(); k++) {
+        const flux::DevScanSphere &sp = fsph[k];
+        const double pp = sp.px * sp.px + sp.py * sp.py + sp.pz * sp.pz;
         const double ppr = (pp - sp.rr) - 8e-6 * (pp + sp.rr) - 1e-30;
         float f = (float)ppr;
         if ((double)f > ppr) f = std::nextafterf(f, -INFINITY);  // rounded down: the bias is never reduced
@@ -315,6 +326,10 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         d.py[k & 1] = (float)sp.py;
         d.pz[k & 1] = (float)sp.pz;
         d.ppr[k & 1] = f;
+        if ((n_uni > 0 && uni_idx[0] == (int)k) || (n_uni > 1 && uni_idx[1] == (int)k)) {
+            d.px[k & 1] = d.py[k & 1] = d.pz[k & 1] = 0.0f;
+            d.ppr[k & 1] = 3.0e38f;
+        }
     }
     const size_t fs_s32_bytes = (fsph32.size() + 4) * sizeof(flux::DevScanSphere32);  // +4 pairs: the filter loads whole groups of 8 spheres
     std::vector<unsigned char> fscene(fs_sph_bytes + fs_pln_bytes + fs_rec_bytes + fs_s32_bytes, 0);
@@ -491,7 +506,13 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.glossy_long = 0;
     for (const flux::DevHitRec &hr : frec_p)
         if (!hr.unit_normal) rp.glossy_long = 1;
-    rp.pad_gl = 0;
+    rp.n_uni = n_uni;
+    rp.uni_idx[0] = uni_idx[0];
+    rp.uni_idx[1] = uni_idx[1];
+    rp.pad_uni = 0;
+    rp.self_skip = (FLUX_SELF_SKIP && !rp.glossy_long) ? 1 : 0;
+    for (const flux::DevScanSphere &sp : fsph)
+        if (!(std::fabs(sp.px) < 1e3 && std::fabs(sp.py) < 1e3 && std::fabs(sp.pz) < 1e3 && sp.rr < 1e6)) rp.self_skip = 0;
     rp.n_sph = (int32_t)fsph.size();
     rp.n_pln = (int32_t)fpln.size();
     *out = c;
@@ -552,6 +573,7 @@ int flux_debug_shade(flux_ctx *ctx, uint64_t n, const double *rays, uint64_t dep
     flux::RenderParams p = ctx->rp;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
     p.glossy_long = 1;  // caller-supplied directions need not be unit vectors
+    p.self_skip = 0;
     if (e == hipSuccess)
         e = flux::launch_shade_rays(p, ctx->math, d_rays, (int)n, (int)depth, (uint32_t)set_index, (uint32_t)sample_index,
                                     d_rgb, d_hit, d_t, nullptr);

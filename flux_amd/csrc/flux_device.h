@@ -12,6 +12,14 @@
 #endif
 
 // wave -> pixel order: 1 = grouped by sample set with one set per XCD at a time (render_body.inc map_wave), 0 = row-major
+// FAST scan: a ray leaving a convex sphere outwards skips that sphere (RenderParams::self_skip); up to FLUX_UNI_SPHERES
+// `invert` spheres are tested wave-uniformly instead of per lane (RenderParams::n_uni)
+#ifndef FLUX_SELF_SKIP
+#define FLUX_SELF_SKIP 1
+#endif
+#ifndef FLUX_UNI_SPHERES
+#define FLUX_UNI_SPHERES 2
+#endif
 #ifndef FLUX_SET_GROUPED
 #define FLUX_SET_GROUPED 1
 #endif
@@ -187,7 +195,13 @@ struct RenderParams {
     int32_t slot_first, slot_stride;
     // FAST: 1 = the scene has a plane whose stored normal is not a unit vector, so a reflected direction may not be one
     // and the Phong lobe may under/overflow: glossy bounces then use the reference's long-form weight (render_body.inc)
-    int32_t glossy_long, pad_gl;
+    int32_t glossy_long;
+    // FAST: 1 = every sphere has |centre| and radius below 1e3 and the scene is not glossy_long: a ray leaving a convex
+    // sphere outwards is then never tested against that sphere (render_body.inc scan_shapes_fast)
+    int32_t self_skip;
+    // FAST with the f32 filter: hit-record indices of up to two `invert` spheres that scan_shapes_fast tests for all
+    // lanes together (their filter records never pass)
+    int32_t n_uni, uni_idx[2], pad_uni;
 };
 
 }  // namespace flux

@@ -362,3 +362,66 @@ def test_split_kernel_with_extreme_cameras(flux, oracle_mod, demo2, lens, focal,
         st = r.stats()
     assert {k: st[k] for k in o.stats()} == o.stats()
     assert max_abs_diff(got, want) < TOL_IMAGE
+
+
+def _env_cases(flux, demo2):
+    """Scenes around the two FAST scan shortcuts: `invert` spheres tested for all lanes at once (ties with a coincident
+    convex twin in either YAML order, three nested environments, a camera outside an environment) and rays that leave a
+    convex sphere outwards skipping that sphere (a camera INSIDE a big convex sphere of every sampled material, so hits come
+    from inside too; a sphere beyond the 1e3 magnitude guard, which switches the shortcut off for the scene)."""
+    import copy
+    base = copy.deepcopy(small_scene(demo2, 24, 18))
+    env = next(s for s in base.shapes if isinstance(s, flux.SphereData) and s.invert)
+    rest = [s for s in base.shapes if s is not env]
+    cases = {}
+    for order in ("convex_first", "inverted_first"):
+        sd = copy.deepcopy(base)
+        twin = flux.SphereData(tuple(env.center), float(env.radius), flux.EmissiveData((0.2, 0.9, 0.3), 2.0), False)
+        e = copy.deepcopy(env)
+        sd.shapes = ([twin, e] if order == "convex_first" else [e, twin]) + copy.deepcopy(rest)
+        cases[order] = sd
+    sd = copy.deepcopy(base)
+    e2, e3 = copy.deepcopy(env), copy.deepcopy(env)
+    e2.radius, e3.radius = float(env.radius) * 0.5, float(env.radius) * 0.25
+    e2.material = flux.MatteData((0.7, 0.8, 0.9), (0, 0, 0), 0.8)
+    e3.material = flux.GlossyReflectiveData(0.7, (0.9, 0.8, 0.7), 30.0)
+    sd.shapes = copy.deepcopy(rest[:3]) + [e3] + copy.deepcopy(rest[3:]) + [e2, copy.deepcopy(env)]
+    cases["nested_environments"] = sd
+    sd = copy.deepcopy(base)
+    small_env = copy.deepcopy(env)
+    small_env.center, small_env.radius = (0.0, 1.0, 0.0), 4.0   # the camera (10 away) looks at it from outside
+    small_env.material = flux.EmissiveData((0.9, 0.9, 0.5), 1.5)
+    sd.shapes = [small_env] + copy.deepcopy(rest)
+    cases["camera_outside_environment"] = sd
+    mats = {"matte": flux.MatteData((0.8, 0.7, 0.6), (0, 0, 0), 0.9),
+            "glossy": flux.GlossyReflectiveData(0.8, (0.9, 0.9, 0.8), 20.0),
+            "reflective": flux.ReflectiveData(0.85, (0.9, 0.95, 1.0))}
+    for name, m in mats.items():
+        sd = copy.deepcopy(base)
+        shell = flux.SphereData((0.0, 0.0, 0.0), 40.0, m, False)     # convex, seen from inside
+        sd.shapes = [shell] + copy.deepcopy(rest)                      # no environment: paths that get out miss
+        cases["inside_convex_" + name] = sd
+    sd = copy.deepcopy(base)
+    sd.shapes = copy.deepcopy(base.shapes) + [flux.SphereData((0.0, 1504.0, 0.0), 1500.0, mats["matte"], False)]
+    cases["beyond_the_magnitude_guard"] = sd
+    return cases
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("case", ["convex_first", "inverted_first", "nested_environments", "camera_outside_environment",
+                                  "inside_convex_matte", "inside_convex_glossy", "inside_convex_reflective",
+                                  "beyond_the_magnitude_guard"])
+def test_environment_and_self_leaving_shortcuts(flux, oracle_mod, demo2, case, variant):
+    sd = _env_cases(flux, demo2)[case]
+    cfg = flux.JobConfiguration(16, 5, 50)   # 256 spp: refill and split kernels
+    o = oracle_mod.Oracle(sd, cfg, seed=4)
+    o.stats(reset=True)
+    want = o.render_frame(threads=8)
+    with flux.Renderer(sd, cfg, seed=4) as r:
+        r.set_kernel(variant)
+        r.enable_stats(True)
+        r.stats(reset=True)
+        got = r.render_frame()
+        st = r.stats()
+    assert {k: st[k] for k in o.stats()} == o.stats()
+    assert max_abs_diff(got, want) < TOL_IMAGE
