@@ -375,6 +375,13 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
             tris.push_back(t);
         }
     }
+    // the traversal addresses node and triangle records by 32-bit byte offsets from their bases (render_body.inc)
+    if (tris.size() * sizeof(flux::DevTri) >= (1ull << 32)) {
+        int code = fail(FLUX_E_INVALID, "%zu triangles exceed the %llu a context can hold", tris.size(),
+                        (unsigned long long)((1ull << 32) / sizeof(flux::DevTri)));
+        delete c;
+        return code;
+    }
     std::vector<flux::DevNodeQ> nodesq;
     flux::build_bvh(tris, nodes, c->bvh);
     flux::quantize_bvh(nodes, nodesq, c->bvh);
