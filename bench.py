@@ -99,10 +99,11 @@ def cpu_baseline(sd, depth, seed, cpu_root):
 
 
 def load_profile(scene_label, kernel_name):
-    """The newest committed rocprofv3 PMC summary (profiles/*pmc*.json, scripts/summarize_profile.py) of this SCENE
+    """The latest committed rocprofv3 PMC summary (profiles/*pmc*.json, scripts/summarize_profile.py) of this SCENE
     and KERNEL (any spp: the counters scale with the sample count, so they are carried per sample)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), key=os.path.getmtime, reverse=True):
+    # newest = highest tag (r02f > r02e > r01j): file times mean nothing in a fresh checkout
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), key=os.path.basename, reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
