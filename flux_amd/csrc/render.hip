@@ -60,8 +60,8 @@
 #define FLUX_BVH_LEAF_VOTE 1      // leave the inner-node loop once the lanes holding a leaf outweigh the descending ones
 #endif
 #ifndef FLUX_BVH_LEAF_NUM
-#define FLUX_BVH_LEAF_NUM 1       // ... i.e. when n_leaf * NUM > n_inner * DEN
-#define FLUX_BVH_LEAF_DEN 1
+#define FLUX_BVH_LEAF_NUM 2       // ... i.e. when n_leaf * NUM > n_inner * DEN (re-swept after the node step got cheaper: 1:1 178.4,
+#define FLUX_BVH_LEAF_DEN 3       //     2:3 175.9, 1:2 176.4, 1:3 179.7, 3:2 178.8 ms at 1024 spp)
 #endif
 #ifndef FLUX_WAVES_PER_EU_FAST
 #define FLUX_WAVES_PER_EU_FAST 5
