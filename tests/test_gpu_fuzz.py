@@ -2,6 +2,8 @@
 spheres, tilted non-unit planes, every material with awkward parameters, coloured backgrounds) rendered by the
 HIP path in both arithmetics and both kernels against the oracle.  Besides the image tolerance, path
 statistics must match exactly -- any ray/primitive or material decision that differs shows up there."""
+import os
+
 import numpy as np
 import pytest
 
@@ -59,7 +61,7 @@ def random_scene(flux, base, rng):
     return sd
 
 
-@pytest.mark.parametrize("chunk", range(8))
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("FLUX_FUZZ_CHUNKS", "8"))))   # a longer soak: FLUX_FUZZ_CHUNKS=80
 def test_random_scenes_against_the_oracle(flux, oracle_mod, demo1, chunk):
     rng = np.random.default_rng(1000 + chunk)
     for case in range(40):
@@ -102,7 +104,7 @@ def test_random_scenes_against_the_oracle(flux, oracle_mod, demo1, chunk):
                         assert not finite.any() or bad.mean() < 0.02, (tag, float(bad.mean()))
 
 
-@pytest.mark.parametrize("chunk", range(4))
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("FLUX_FUZZ_MESH_CHUNKS", "4"))))
 def test_random_meshes_against_the_oracle(flux, oracle_mod, demo1, chunk):
     """The same with triangle soups added (extension): the BVH state-machine kernel (64 spp), the inline BVH
     (static kernel, STRICT) and brute force must all take the oracle's decisions."""
