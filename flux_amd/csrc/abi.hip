@@ -166,6 +166,8 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     if (set_stride < 1 || first_set >= set_stride)
         return fail(FLUX_E_INVALID, "sample-set share: need set_stride >= 1 and first_set < set_stride, got %llu / %llu",
                     (unsigned long long)first_set, (unsigned long long)set_stride);
+    if (set_stride > 0xffffffffull)  // stored as 32-bit (SetRange); first_set < set_stride is then in range too
+        return fail(FLUX_E_INVALID, "sample-set share: set_stride %llu exceeds 2^32 - 1", (unsigned long long)set_stride);
     if (cfg->sample_root < 1 || cfg->sample_root > 4096)
         return fail(FLUX_E_INVALID, "sample_root must be in [1,4096], got %llu",
                     (unsigned long long)cfg->sample_root);
@@ -384,7 +386,11 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     }
     std::vector<flux::DevNodeQ> nodesq;
     flux::build_bvh(tris, nodes, c->bvh);
-    flux::quantize_bvh(nodes, nodesq, c->bvh);
+    if (!flux::quantize_bvh(nodes, nodesq, c->bvh)) {
+        int code = fail(FLUX_E_INVALID, "BVH quantisation lost containment (mesh coordinates beyond the 16-bit grid's reach)");
+        delete c;
+        return code;
+    }
     if (c->bvh.max_depth > (uint64_t)flux::kBvhMaxDepth) {
         int code = fail(FLUX_E_INVALID, "BVH depth %llu exceeds %d (degenerate mesh)",
                         (unsigned long long)c->bvh.max_depth, flux::kBvhMaxDepth);
@@ -528,19 +534,26 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
 
 static bool holds_all_sets(const flux_ctx *c) { return c->sets.stride == 1 && c->sets.first == 0; }
 
-// Dynamic + static LDS one block of `threads` threads needs: STRICT keeps the (f,s) recursion stack (4 doubles per level
-// per lane), mesh scenes the BVH traversal stack (one int per level per lane, none for brute force), the refill / split
-// kernels a few static words (per-wave totals).  64 KiB per block is the launch limit.
-static int check_lds_budget(const flux_ctx *ctx, size_t threads, const char *what) {
-    const size_t strict = ctx->math == FLUX_MATH_STRICT ? (size_t)ctx->D * 4 * threads * sizeof(double) : 0;
-    const bool bvh = ctx->d_tris != nullptr && ctx->traversal == FLUX_TRAVERSE_BVH;
-    const size_t stack = bvh ? (size_t)ctx->bvh.max_depth * threads * sizeof(int) : 0;
+// LDS one block of the kernel about to be launched needs: asked of the launch plan itself (render_body.inc plan_render_impl:
+// STRICT keeps the (f,s) recursion stack, 4 doubles per level per lane; mesh scenes the BVH traversal stack, one int per
+// level per lane -- 64 lanes in the FAST state-machine kernel, the block's in the others --; the split kernel its path
+// queues), plus the few static words of the refill / split kernels.  64 KiB per block is the launch limit.
+static int check_lds_budget(const flux_ctx *ctx, const flux::RenderParams &p, const char *what) {
+    const size_t dyn = flux::render_lds_bytes(p, ctx->variant, ctx->math);
     const size_t fixed = 512;
-    if (strict + stack + fixed > 64 * 1024)
-        return fail(FLUX_E_INVALID, "%s: %zu B of LDS per block (recursion stack %zu B for max_trace_depth %u%s, BVH stack %zu B "
-                    "for depth %llu) exceed the 64 KiB limit; use FLUX_MATH_FAST or a smaller max_trace_depth", what,
-                    strict + stack + fixed, strict, ctx->D, ctx->math == FLUX_MATH_STRICT ? " in FLUX_MATH_STRICT" : "", stack,
-                    (unsigned long long)ctx->bvh.max_depth);
+    if (dyn + fixed > 64 * 1024)
+        return fail(FLUX_E_INVALID, "%s: %zu B of LDS per block (max_trace_depth %u%s, BVH depth %llu) exceed the 64 KiB limit; "
+                    "use FLUX_MATH_FAST or a smaller max_trace_depth", what, dyn + fixed, ctx->D,
+                    ctx->math == FLUX_MATH_STRICT ? " in FLUX_MATH_STRICT: 32 B of recursion stack per level and lane" : "",
+                    (unsigned long long)(p.bvh_stack > 0 ? ctx->bvh.max_depth : 0));
+    return FLUX_OK;
+}
+// flux_debug_shade: 64-thread blocks, STRICT recursion stack + per-lane BVH stack (render_body.inc launch_shade_rays_impl)
+static int check_lds_budget_rays(const flux_ctx *ctx, const flux::RenderParams &p) {
+    const size_t strict = ctx->math == FLUX_MATH_STRICT ? (size_t)ctx->D * 4 * 64 * sizeof(double) : 0;
+    const size_t stack = p.n_tris > 0 ? (size_t)p.bvh_stack * 64 * sizeof(int) : 0;
+    if (strict + stack > 64 * 1024)
+        return fail(FLUX_E_INVALID, "flux_debug_shade: %zu B of LDS per block exceed the 64 KiB limit", strict + stack);
     return FLUX_OK;
 }
 
@@ -567,7 +580,6 @@ int flux_debug_shade(flux_ctx *ctx, uint64_t n, const double *rays, uint64_t dep
     if (!holds_all_sets(ctx)) return fail(FLUX_E_INVALID, "this context holds a share of the sample sets only (flux_ctx_create_sets)");
     if (depth < 1 || set_index >= ctx->S || sample_index >= ctx->N)
         return fail(FLUX_E_INVALID, "depth >= 1, set_index < %u and sample_index < %u required", ctx->S, ctx->N);
-    if (int rc = check_lds_budget(ctx, 64, "flux_debug_shade")) return rc;
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(FLUX_E_DEVICE, "hipSetDevice(%d) failed", ctx->device);
     double *d_rays = nullptr, *d_rgb = nullptr, *d_t = nullptr;
@@ -581,6 +593,13 @@ int flux_debug_shade(flux_ctx *ctx, uint64_t n, const double *rays, uint64_t dep
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
     p.glossy_long = 1;  // caller-supplied directions need not be unit vectors
     p.self_skip = 0;
+    if (int rc = check_lds_budget_rays(ctx, p)) {
+        (void)hipFree(d_rays);
+        (void)hipFree(d_rgb);
+        (void)hipFree(d_t);
+        (void)hipFree(d_hit);
+        return rc;
+    }
     if (e == hipSuccess)
         e = flux::launch_shade_rays(p, ctx->math, d_rays, (int)n, (int)depth, (uint32_t)set_index, (uint32_t)sample_index,
                                     d_rgb, d_hit, d_t, nullptr);
@@ -664,11 +683,7 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
     p.num_rows = (int32_t)num_rows;
     p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
-    {
-        size_t threads = 64;  // 64 * K, K as in launch_render (refill / split blocks hold up to FLUX_MAX_WAVES_PER_PIXEL waves)
-        while (threads * 2 <= 64 * FLUX_MAX_WAVES_PER_PIXEL && threads * 2 * (FLUX_MIN_SAMPLES_PER_WAVE / 64) <= ctx->N) threads *= 2;
-        if (int rc = check_lds_budget(ctx, threads, "flux_render_rows")) return rc;
-    }
+    if (int rc = check_lds_budget(ctx, p, "flux_render_rows")) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
     HIP_TRY(hipEventRecord(ctx->ev1, stream));
@@ -708,7 +723,7 @@ int flux_render_sets_device(flux_ctx *ctx, uint64_t first_set, uint64_t set_stri
     p.slot_stride = (int32_t)(set_stride / ctx->sets.stride);
     p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
-    if (int rc = check_lds_budget(ctx, 64 * FLUX_MAX_WAVES_PER_PIXEL, "flux_render_sets_device")) return rc;
+    if (int rc = check_lds_budget(ctx, p, "flux_render_sets_device")) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
     HIP_TRY(hipEventRecord(ctx->ev1, stream));

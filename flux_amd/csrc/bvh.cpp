@@ -279,9 +279,9 @@ void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &
                         std::chrono::steady_clock::now() - t0).count();
 }
 
-void quantize_bvh(const std::vector<DevNode> &nodes, std::vector<DevNodeQ> &out, BvhInfo &info) {
+bool quantize_bvh(const std::vector<DevNode> &nodes, std::vector<DevNodeQ> &out, BvhInfo &info) {
     out.clear();
-    if (nodes.empty()) return;
+    if (nodes.empty()) return true;
     // grid over all FINITE box corners (the one-leaf tree's empty slot is an inverted infinite box)
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     auto grow = [&](const float *l, const float *h) {
@@ -294,17 +294,29 @@ void quantize_bvh(const std::vector<DevNode> &nodes, std::vector<DevNodeQ> &out,
         grow(N.lo0, N.hi0);
         grow(N.lo1, N.hi1);
     }
-    // grid: value(q) = qmin + q * qstep with qmin ONE QUANTUM BELOW the lowest corner, so that q = 1 is the lowest corner,
-    // the highest is at most q = 65534, and 0 / 65535 remain for the extra quantum every box is widened by
+    // grid: value(q) = qmin + q * qstep with qmin AT LEAST ONE QUANTUM BELOW the lowest corner (so q >= 1 there) and the
+    // step sized from (highest corner - qmin), so that the highest corner lands at q <= 65533 and 0 / 65534.. remain for the
+    // extra quantum every box is widened by.  qmin is fixed FIRST: for a mesh far from the origin relative to its extent
+    // (ulp_f32(lo) > step) rounding qmin down moves it by many quanta, and a step sized from (hi - lo) alone would push
+    // the top corners past 65535, where the clamp breaks containment.
     for (int a = 0; a < 3; a++) {
         if (!(hi[a] >= lo[a])) lo[a] = hi[a] = 0.0f;
-        const double ext = (double)hi[a] - (double)lo[a];
-        float st = (float)(ext / 65533.0 * (1.0 + 1e-6));
+        const double L = (double)lo[a], H = (double)hi[a];
+        auto upf = [](double x) {
+            float f = (float)x;
+            if ((double)f < x) f = std::nextafterf(f, INFINITY);
+            return f;
+        };
+        float st = upf(std::max(H - L, 1e-30) / 65530.0);
         if (!(st > 0.0f)) st = 1e-30f;
-        while ((double)st * 65533.0 < ext) st = std::nextafterf(st, INFINITY);
+        float org = (float)(L - (double)st);
+        for (int it = 0; it < 64; ++it) {
+            while ((double)org + (double)st > L) org = std::nextafterf(org, -INFINITY);
+            const float need = upf((H - (double)org) / 65532.0);
+            if (need <= st) break;
+            st = need;  // a larger step: re-check that qmin is still a quantum below the lowest corner
+        }
         info.qstep[a] = st;
-        float org = (float)((double)lo[a] - (double)st);
-        while ((double)org + (double)st > (double)lo[a]) org = std::nextafterf(org, -INFINITY);
         info.qmin[a] = org;
     }
     auto qlo = [&](float v, int a) -> uint16_t {  // a grid point at least one quantum below v
@@ -330,6 +342,21 @@ void quantize_bvh(const std::vector<DevNode> &nodes, std::vector<DevNodeQ> &out,
         Q.child0 = N.child0;
         Q.child1 = N.child1;
     }
+    // the invariant the traversal relies on, verified: every quantised box contains its f32 box (grid values in exact
+    // arithmetic; the slab test's padding covers the device's f32 evaluation, render_body.inc)
+    auto val = [&](uint16_t q, int a) { return (double)info.qmin[a] + (double)q * (double)info.qstep[a]; };
+    for (size_t k = 0; k < nodes.size(); k++) {
+        const DevNode &N = nodes[k];
+        const DevNodeQ &Q = out[k];
+        for (int a = 0; a < 3; a++) {
+            const bool ok0 = !std::isfinite(N.lo0[a]) || !std::isfinite(N.hi0[a]) ||
+                             (val(Q.lo0[a], a) <= (double)N.lo0[a] && val(Q.hi0[a], a) >= (double)N.hi0[a]);
+            const bool ok1 = !std::isfinite(N.lo1[a]) || !std::isfinite(N.hi1[a]) ||
+                             (val(Q.lo1[a], a) <= (double)N.lo1[a] && val(Q.hi1[a], a) >= (double)N.hi1[a]);
+            if (!ok0 || !ok1) return false;
+        }
+    }
+    return true;
 }
 
 }  // namespace flux

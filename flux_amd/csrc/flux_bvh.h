@@ -60,7 +60,8 @@ struct BvhInfo {
 // Binned-SAH top-down build.  `tris` is reordered into leaf order (ids keep the original order).
 void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &info);
 
-// `nodes` on the 16-bit grid (fills info.qmin / qstep).  Every quantised box CONTAINS the f32 box it comes from.
-void quantize_bvh(const std::vector<DevNode> &nodes, std::vector<DevNodeQ> &out, BvhInfo &info);
+// `nodes` on the 16-bit grid (fills info.qmin / qstep).  Every quantised box CONTAINS the f32 box it comes from; the
+// function verifies that and returns false if it does not hold (the caller refuses the mesh).
+bool quantize_bvh(const std::vector<DevNode> &nodes, std::vector<DevNodeQ> &out, BvhInfo &info);
 
 }  // namespace flux

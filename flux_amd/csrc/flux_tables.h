@@ -24,6 +24,8 @@ hipError_t hemi_to_aos(size_t SD, size_t N, const double *in, double *out, hipSt
 // Camera::render (trace.rs:53-97).  variant: FLUX_KERNEL_STATIC / FLUX_KERNEL_REFILL;
 // math: FLUX_MATH_FAST / FLUX_MATH_STRICT (render_body.inc).
 hipError_t launch_render(const RenderParams &p, int variant, int math, hipStream_t stream);
+// dynamic LDS per block of the kernel launch_render picks for these parameters (render.hip)
+size_t render_lds_bytes(const RenderParams &p, int variant, int math);
 
 // Scene::shade for caller-supplied rays (device pointers; rays = n x (origin, direction)).
 hipError_t launch_shade_rays(const RenderParams &p, int math, const double *d_rays, int n, int depth, uint32_t set,

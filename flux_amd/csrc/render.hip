@@ -121,6 +121,11 @@ hipError_t launch_render(const RenderParams &p, int variant, int math, hipStream
     return fast::launch_render_impl(p, variant, stream);
 }
 
+// dynamic LDS per block of the kernel launch_render would pick (host-side budget check)
+size_t render_lds_bytes(const RenderParams &p, int variant, int math) {
+    return math == FLUX_MATH_STRICT ? strict::plan_render_impl(p, variant).lds : fast::plan_render_impl(p, variant).lds;
+}
+
 hipError_t launch_shade_rays(const RenderParams &p, int math, const double *d_rays, int n, int depth, uint32_t set,
                              uint32_t index, double *d_rgb, int *d_hit, double *d_t, hipStream_t stream) {
     if (math == FLUX_MATH_STRICT) return strict::launch_shade_rays_impl(p, d_rays, n, depth, set, index, d_rgb, d_hit, d_t, stream);

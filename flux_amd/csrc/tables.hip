@@ -241,6 +241,13 @@ hipError_t generate_tables(uint64_t seed, uint32_t S, SetRange sets, uint32_t D,
     const uint32_t So = sets.count;  // sets held by this context
     uint16_t *cmj_perms = nullptr, *mj_perms = nullptr;
     hipError_t e;
+    if (So == 0) {  // an empty share (more ranks than sample sets): no per-set tables, only who-uses-which-set
+        row_perm_kernel<<<blocks_for(H, 64), 64, 0, stream>>>(seed, H, S, rowperm);
+        inv_perm_kernel<<<blocks_for((size_t)H * S, 256), 256, 0, stream>>>(H, S, rowperm, invperm);
+        e = hipGetLastError();
+        const hipError_t e2 = hipStreamSynchronize(stream);
+        return e != hipSuccess ? e : e2;
+    }
     size_t cmj_elems = (size_t)So * 2 * n;
     size_t mj_elems = (size_t)So * D * 2 * n * n;
     if ((e = hipMalloc(&cmj_perms, 2 * cmj_elems * sizeof(uint16_t))) != hipSuccess) return e;

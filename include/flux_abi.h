@@ -197,8 +197,10 @@ int flux_ctx_set_kernel(flux_ctx *ctx, int variant);
 /* Arithmetic of the render kernels -- both FP64 end to end, both checked against the oracle at the
  * north-star tolerance (1e-4 per channel):
  *   FLUX_MATH_FAST (default): the reference's estimator evaluated for the machine -- FMA contraction,
- *       division/sqrt/pow/sincos from flux_math.h (<= ~2 ulp), no BoundingBox::hit pre-test (implied by
- *       the sphere quadratic), path throughput multiplied front to back, bounce weights in closed form.  The glossy
+ *       division/sqrt/pow/sincos from flux_math.h (<= ~2 ulp), no BoundingBox::hit pre-test (the sphere quadratic
+ *       implies its answer, except that a ray with direction.z == 0 whose origin lies on a z face of a sphere's box
+ *       misses that sphere -- the box's 0 * inf = NaN, shapes.rs:121-130 -- which is reproduced by an explicit rule),
+ *       path throughput multiplied front to back, bounce weights in closed form.  The glossy
  *       closed form (cs ks: the Phong lobe cancels) is used only where the lobe cannot under/overflow, i.e. in scenes
  *       whose plane normals are unit vectors; a scene with a non-unit plane normal gets the reference's long form for
  *       every glossy bounce, so the NaN pixels such a scene has in the reference appear here too;

@@ -1,10 +1,11 @@
 /*
  * flux_oracle.c -- CPU restatement of fluxcore's per-pixel render loop.
  *
- * TEST INFRASTRUCTURE ONLY (see flux_oracle.h).  PARITY UNPINNED: the
- * reference has no tests / golden vectors and a non-reproducible RNG; this
- * file is pinned by hand-derived KATs and a statistical comparison with the
- * reference's demo.png only.
+ * TEST INFRASTRUCTURE ONLY (see flux_oracle.h).  PIN: the reference's only
+ * published output, demo.png, at its real 16-bit precision (a statistical
+ * pin by necessity -- the reference seeds its RNG from OS entropy and never
+ * reproduces an image itself), plus hand-derived KATs; what the pin covers
+ * and what it cannot is spelled out in flux_oracle.h and DESIGN.md section 2.
  *
  * Structure deliberately follows the reference's own decomposition (recursive
  * shade, explicit base-grid / shuffle / transpose sampler pipeline, per-shape

@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg -- never by anything under flux_amd/.
-PARITY UNPINNED: see oracle/flux_oracle.h.
+Pinned to the reference's demo.png at 16 bits (statistical) + hand-derived KATs: see oracle/flux_oracle.h.
 """
 import ctypes as C
 import os

@@ -74,7 +74,7 @@ for name, cs in counters.items():
         main = k
 if main and "FETCH_SIZE" in main and "WRITE_SIZE" in main:
     # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in units of 1024 B
-    out["hbm_bytes_per_launch_raw"] = (main["FETCH_SIZE"] + main["WRITE_SIZE"]) * 1024.0
+    out["l2_miss_bytes_per_launch_raw"] = (main["FETCH_SIZE"] + main["WRITE_SIZE"]) * 1024.0
     # correction factor for FETCH_SIZE: measured by the calibration kernels of this very run when present
     # (both of this kernel's access widths, 16 B and 8 B per lane, read exactly 1/2 on gfx950), else argv/1.0
     scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
@@ -82,7 +82,10 @@ if main and "FETCH_SIZE" in main and "WRITE_SIZE" in main:
         ratios = [float(1 << 30) / x for v in calib.values() for x in v if x]
         scale = sum(ratios) / len(ratios)
     out["fetch_scale"] = scale
-    out["hbm_bytes_per_launch"] = (main["FETCH_SIZE"] * scale + main["WRITE_SIZE"]) * 1024.0
+    # bytes that left the L2s towards the fabric: one 128-B line per miss, tallied at 64 B by FETCH_SIZE (streams AND divergent
+    # gathers: profiles/r03_gather_calibration.json); Infinity-Cache hits are counted, so this bounds HBM bytes from above
+    out["l2_miss_bytes_per_launch"] = (main["FETCH_SIZE"] * scale + main["WRITE_SIZE"]) * 1024.0
+    out["hbm_bytes_per_launch"] = None  # no DRAM-side counter on gfx950
 if main and "SQ_ACTIVE_INST_VALU" in main and "SQ_BUSY_CYCLES" in main and main["SQ_BUSY_CYCLES"]:
     # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader
     # engines (MI355X_MICROARCH.md): busy fraction of the 1024 SIMDs' cycles spent issuing VALU instructions

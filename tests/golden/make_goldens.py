@@ -3,7 +3,8 @@
 demo1 and demo2 geometry at 64x48 (pixel_size scaled to keep the field of view), 16 spp
 (sample_root 4), depth 5, seed 1 -> float64 [48][64][3].  They pin CPU<->GPU agreement on the GPU
 box and guard the oracle itself against accidental edits.  Not reference output (the reference is
-non-deterministic and cannot be built here): parity stays "unpinned" in the prompt's sense.
+non-deterministic and cannot be built here): these are regression data; the PIN to the reference is demo.png at
+16 bits (make_demo2_ref16.py, oracle/flux_oracle.h).
 """
 import os
 import sys

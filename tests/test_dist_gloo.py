@@ -21,6 +21,22 @@ def _free_port():
     return p
 
 
+def _spawn(fn, world, *args):
+    """mp.spawn on a fresh port; one retry on another port if the rendezvous itself failed (the port found by
+    _free_port can be taken by another process between the probe and the bind)."""
+    for attempt in range(2):
+        port = _free_port()
+        try:
+            mp.spawn(fn, args=(world, port) + args, nprocs=world, join=True)
+            return
+        except Exception as ex:  # noqa: BLE001
+            msg = str(ex)
+            if attempt == 0 and any(k in msg for k in ("address already in use", "Address already in use", "EADDRINUSE",
+                                                       "DistNetworkError", "Connection reset", "timed out")):
+                continue
+            raise
+
+
 def _worker(rank, world, port, height, out_dir):
     import sys
     sys.path.insert(0, ROOT)
@@ -49,8 +65,7 @@ def _worker(rank, world, port, height, out_dir):
 
 @pytest.mark.parametrize("world,height", [(2, 16), (2, 15), (3, 16)])
 def test_sharded_frame_equals_single(tmp_path, world, height):
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, height, str(tmp_path)), nprocs=world, join=True)
+    _spawn(_worker, world, height, str(tmp_path))
     counts = []
     for r in range(world):
         ok, cnt = np.load(str(tmp_path / f"ok_{r}.npy"))
@@ -106,8 +121,7 @@ def _set_worker(rank, world, port, width, out_dir):
 def test_set_sharded_frame_equals_single(tmp_path, world, width):
     """SetSharder: ranks own sample sets (s % G == rank), one all_gather, reassembly through the row permutation;
     ragged set counts (21 sets over 2 ranks, 20 over 3) are padded."""
-    port = _free_port()
-    mp.spawn(_set_worker, args=(world, port, width, str(tmp_path)), nprocs=world, join=True)
+    _spawn(_set_worker, world, width, str(tmp_path))
     counts = []
     for r in range(world):
         ok, cnt = np.load(str(tmp_path / f"ok_{r}.npy"))

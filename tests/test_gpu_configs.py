@@ -3,12 +3,15 @@ them in seconds), plus the pieces that only exist for them:
 
  * config 2  scenes/demo1.yml 800x600 @256 spp (sample_root 16): determinism, kernel variants equal up to summation
              order, finite / [0,1], path-statistics identities and their equality across kernels;
+ * config 3  scenes/demo2.yml 800x600 @1024 spp (sample_root 32), the FULL frame: determinism, split == refill == static up to
+             summation order with identical path statistics, finite / [0,1], rows 0-1 and 298-301 against the oracle;
  * config 4  the per-rank contexts of the set-sharded frame (flux_ctx_create_sets): same tables, same pixels as the
              full context; and the "misses" of an ENCLOSED scene -- rays that start within T_MIN of the environment
              sphere (scene.rs:156-160 + constants.rs:4: the hit is rejected) -- agree with the oracle ray by ray;
  * config 5  the procedural 1M-triangle height field (extension; flux_amd/procedural.py): BVH traversal == brute force
              over all 1,000,000 triangles on thousands of rays in both arithmetics, identical path statistics on a
-             pixel window, and the same horizon-miss behaviour.
+             pixel window, the same horizon-miss behaviour, and ONE FULL 4096-spp FRAME through render_bvh_kernel
+             (determinism, statistics identities, finite / [0,1], rows 330-331 against the static kernel).
 """
 import numpy as np
 import pytest
@@ -54,6 +57,40 @@ def test_config2_full_size_properties(flux, demo1, math):
             assert np.array_equal(r.render_rows(u.row_start, u.row_end), a[u.row_start:u.row_end + 1])
 
 
+# ------------------------------------------------------------------------------------------------ config 3
+def test_config3_full_frame(flux, oracle_mod, demo2):
+    """BASELINE config 3 as stated: scenes/demo2.yml, the whole 800x600 frame at 1024 spp (Camera::render over all rows,
+    trace.rs:62-91).  Size-independent properties on the full frame, and six rows -- the two at the top (the horizon) and
+    four through the middle of the spheres -- against the oracle at the north-star tolerance."""
+    cfg = flux.JobConfiguration(32, 5, 50)
+    with flux.Renderer(demo2, cfg, seed=1) as r:
+        r.enable_stats(True)
+        frames, stats = {}, {}
+        for name, variant in (("split", flux.KERNEL_SPLIT), ("refill", flux.KERNEL_REFILL), ("static", flux.KERNEL_STATIC)):
+            r.set_kernel(variant)
+            r.stats(reset=True)
+            frames[name] = r.render_frame()
+            stats[name] = r.stats(reset=True)
+        r.set_kernel(flux.KERNEL_DEFAULT)
+        r.enable_stats(False)
+        again = r.render_frame()
+    a = frames["split"]
+    assert a.shape == (600, 800, 3)
+    assert np.array_equal(a, again)                                     # the default kernel IS the split kernel; bitwise repeatable
+    assert np.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 1.0   # max_to_one (color.rs:35-44)
+    for name in ("refill", "static"):
+        assert max_abs_diff(a, frames[name]) < 1e-12, name              # same samples, another fixed summation order
+        assert stats[name] == stats["split"], name                      # every hit / material decision identical
+    st = stats["split"]
+    assert st["samples"] == 800 * 600 * 1024
+    assert st["segments"] == st["matte_bounces"] + st["glossy_bounces"] + st["specular_bounces"] + st["emissive_hits"] + st["misses"]
+    assert st["samples"] == st["emissive_hits"] + st["misses"] + st["depth_exhausted"]
+    rows = np.array([0, 1, 298, 299, 300, 301], dtype=np.int32)
+    want = oracle_mod.Oracle(demo2, cfg, seed=1).render_row_list(rows)   # 6 x 800 x 1024 = 4.9 M samples on the CPU
+    assert max_abs_diff(a[rows], want) < 1e-4
+    assert np.percentile(np.abs(a[rows] - want), 99.9) < 1e-9
+
+
 # ------------------------------------------------------------------------------------------------ config 4
 @pytest.mark.parametrize("world", [1, 3, 8])
 def test_set_share_context_equals_full_context(flux, demo2, small, world):
@@ -86,6 +123,15 @@ def test_set_share_context_equals_full_context(flux, demo2, small, world):
             torch.cuda.synchronize()
     with pytest.raises(flux.FluxError):
         flux.Renderer(sd, cfg, seed=3, set_share=(3, 3))                     # first_set < set_stride
+    with pytest.raises(flux.FluxError):
+        flux.Renderer(sd, cfg, seed=3, set_share=(0, 1 << 32))               # the stride is held in 32 bits
+    # more ranks than sample sets: rank 45 of 48 owns no set of this 40-set image -- an EMPTY share is a valid context
+    # (no per-set tables, the row permutations only) whose render is a no-op
+    with flux.Renderer(sd, cfg, seed=3, set_share=(45, 48)) as empty, flux.Renderer(sd, cfg, seed=3) as full:
+        assert empty.table(flux._lib.TABLE_PIXEL).shape[0] == 0
+        assert np.array_equal(empty.row_perm(5), full.row_perm(5))
+        empty.render_sets_device(45, 48, 0, 0)
+        assert empty.device_bytes() < full.device_bytes()
 
 
 def _horizon_rays(rng, n, radius, y_plane):
@@ -244,3 +290,33 @@ def test_config5_state_machine_kernel_and_misses(flux, oracle_mod, hf_scene):
     sub = np.concatenate([np.flatnonzero(hit_b == -1)[:24], np.flatnonzero(hit_b != -1)[:24]])
     want = np.array([orc.scene_hit(o[k], d[k])[0] for k in sub])      # ~5 ms per ray on the CPU: a sample
     assert np.array_equal(hit_b[sub], want)
+
+
+def test_config5_full_frame_at_4096_spp(flux, hf_scene):
+    """BASELINE config 5 as stated, on the one GPU a test box has: the whole 800x600 frame of the 1,000,000-triangle scene at
+    4096 spp through render_bvh_kernel (1.97 G camera paths).  No CPU comparison is possible at this size (the oracle scans
+    every triangle per ray), so: bitwise determinism, the statistics identities, finite / [0,1]; and rows 330-331 (the field's
+    far edge and the spheres) at the same 4096 spp against the STATIC kernel, whose inline BVH walk shares nothing with the
+    state machine but the hit rule -- equal statistics, images to summation order (the static kernel itself equals brute
+    force bit for bit: test_config5_pixel_window_statistics)."""
+    with flux.Renderer(hf_scene, flux.JobConfiguration(64, 5, 50), seed=1) as r:
+        a = r.render_frame()
+        b = r.render_frame()
+        assert np.array_equal(a, b)
+        assert a.shape == (600, 800, 3) and np.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 1.0
+        r.enable_stats(True)
+        r.stats(reset=True)
+        c = r.render_frame()
+        st = r.stats(reset=True)
+        assert np.array_equal(a, c)                                     # counting statistics changes no pixel
+        assert st["samples"] == 800 * 600 * 4096
+        assert st["segments"] == st["matte_bounces"] + st["glossy_bounces"] + st["specular_bounces"] + st["emissive_hits"] + st["misses"]
+        assert st["samples"] == st["emissive_hits"] + st["misses"] + st["depth_exhausted"]
+        assert st["bvh_nodes"] > 10 * st["segments"] and st["tris_tested"] > st["segments"]
+        band, stb = r.render_rows(330, 331), r.stats(reset=True)
+        r.set_kernel(flux.KERNEL_STATIC)
+        ref, sts = r.render_rows(330, 331), r.stats(reset=True)
+        drop = ("bvh_nodes", "tris_tested")                             # the two kernels order their traversals differently
+        assert {k: v for k, v in stb.items() if k not in drop} == {k: v for k, v in sts.items() if k not in drop}
+        assert np.array_equal(band, a[330:332])
+        assert max_abs_diff(band, ref) < 1e-12

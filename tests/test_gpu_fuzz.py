@@ -92,7 +92,8 @@ def test_random_scenes_against_the_oracle(flux, oracle_mod, demo1, chunk):
                     # overflows, which needs a non-unit plane normal (for unit normals lobe >= 1 - y) -- its long
                     # form f (n.wi)/pdf yields NaN (0 * inf) or a value degraded by subnormal rounding.  STRICT
                     # reproduces exactly that; FAST uses the closed-form weight only for unit reflected directions
-                    # and the long form otherwise (FLUX_GLOSSY_LONG_FORM), so its NaN pixels are the reference's too.
+                    # and the long form otherwise (RenderParams::glossy_long, a scene-level switch set in abi.hip when a
+                    # plane's stored normal is not a unit vector), so its NaN pixels are the reference's too.
                     assert np.array_equal(np.isfinite(got), finite), tag          # NaN pixels: the reference's, in BOTH modes
                     if math == flux.MATH_STRICT or finite.all():
                         assert max_abs_diff(got[finite], want[finite]) < 1e-4 if finite.any() else True, tag
@@ -100,8 +101,14 @@ def test_random_scenes_against_the_oracle(flux, oracle_mod, demo1, chunk):
                         # FAST next to NaN pixels: the same long form (r.wi)^e, but a lobe in the subnormal range is
                         # "degraded" differently by its own arithmetic (front-to-back throughput vs the reference's
                         # recursion order), so finite neighbours are compared loosely
-                        bad = np.abs(got[finite] - want[finite]) > 1e-4
+                        # -- loosely, but not blindly: few of them (a slip in the long form itself would move EVERY glossy
+                        # pixel of such a scene, far more than 2 %), and each within the factor a subnormal lobe's last
+                        # bits can change one sample's weight by (its products with n.wi lose bits in the subnormal range: a factor of a few, never a sign flip or an order of magnitude)
+                        dev = np.abs(got[finite] - want[finite])
+                        bad = dev > 1e-4
                         assert not finite.any() or bad.mean() < 0.02, (tag, float(bad.mean()))
+                        scale = np.maximum(np.abs(got[finite]), np.abs(want[finite]))
+                        assert np.all(dev[bad] <= 0.8 * scale[bad] + 1e-4), (tag, float((dev[bad] / (scale[bad] + 1e-300)).max()))
 
 
 @pytest.mark.parametrize("chunk", range(int(os.environ.get("FLUX_FUZZ_MESH_CHUNKS", "4"))))

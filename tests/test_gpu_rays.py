@@ -70,6 +70,17 @@ def test_reference_corner_cases(flux, oracle_mod, demo2, math):
         ((0.0, 150.0, 0.0), (0.0, 1.0, 0.0)),    # outside the environment sphere looking away: miss -> background
         ((0.0, 150.0, 0.0), (0.0, -1.0, 0.0)),   # outside looking in: hits its outer side (emits only from inside)
         ((-9.0, 7.0, 8.0 - 5.0 - 1e-9), (0.0, 0.0, 1.0)),  # just outside the light sphere: distance below T_MIN
+        # BoundingBox::hit's z-slab NaN (shapes.rs:121-130): direction.z == 0 and the origin ON a z face of the box of the
+        # sphere at (1,1,2): (corner.z - oz) * (1/0) = 0 * inf = NaN comes out of the reference's max/min forms as t0 resp.
+        # t1, `t0 < t1` is false and the sphere is MISSED although the quadratic has disc = 0, t = 6 (the ray is tangent).
+        # The same tangent through an x or y face hits: those NaNs are dropped by the max/min forms.
+        ((-5.0, 1.0, 1.0), (1.0, 0.0, 0.0)),     # tz_min NaN (corner0.z == oz)
+        ((-5.0, 1.0, 3.0), (1.0, 0.0, 0.0)),     # tz_max NaN (corner1.z == oz)
+        ((-5.0, 1.0, 3.0), (1.0, 0.0, -0.0)),    # 1/dz = -inf: the slabs swap, still NaN
+        ((-5.0, 1.0, 1.0), (-1.0, 0.0, 0.0)),    # looking away: a miss either way
+        ((1.0, 0.0 + 1e-3, 2.0 - 6.0), (0.0, 0.0, 1.0)),  # control: tangent at the sphere's lowest point through its y face
+        ((1.0, 2.0, 2.0 - 6.0), (0.0, 0.0, 1.0)),          # control: exactly ON the y face (ty NaN is dropped): tangent, decided by the quadratic
+        ((2.0, 1.0, 2.0 - 6.0), (0.0, 0.0, 1.0)),          # control: exactly ON the x face
     ]
     origins = np.array([a for a, _ in rays])
     dirs = np.array([b for _, b in rays])
@@ -79,6 +90,7 @@ def test_reference_corner_cases(flux, oracle_mod, demo2, math):
     assert hit[5] == 4 and abs(t[5] - 2.0) < 1e-12 and hit[6] == 4 and abs(t[6] - 1.0) < 1e-12
     assert hit[11] == 0 and abs(t[11] - 50.0) < 1e-12 and hit[12] == -1 and hit[13] == 0
     assert np.array_equal(rgb[12], sd.background)
+    assert hit[15] != 5 and hit[16] != 5 and hit[17] != 5  # the z-slab NaN: sphere #5 (centre (1,1,2)) is missed, as in the reference
     # the plane alone: the parallel ray with a positive numerator "hits" it at t = +inf (Plane::hit's quirk)
     only_plane = copy.deepcopy(sd)
     only_plane.shapes = [sd.shapes[12]]

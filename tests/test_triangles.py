@@ -132,6 +132,57 @@ def test_bvh_equals_bruteforce_equals_oracle(flux, oracle_mod, demo2, nx, nz, va
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("offset", [(5.0e3, 0.0, 0.0), (0.0, -2.0e4, 7.0e3), (1.0e6, 1.0e6, -1.0e6)])
+def test_bvh_of_a_mesh_far_from_the_origin(flux, demo2, offset):
+    """quantize_bvh's 16-bit grid when the mesh sits hundreds of extents from the origin (ulp_f32(lo) > grid step: qmin
+    rounds down by many quanta): every quantised box must still contain its f32 box, i.e. the state-machine
+    kernel (DevNodeQ), the inline walk (DevNode) and brute force must agree -- first hits on rays aimed at the mesh, path
+    statistics and images of a frame whose camera travels with the mesh."""
+    from flux_amd.procedural import heightfield_mesh
+    from flux_amd.scene import SphereData, PlaneData
+    off = np.array(offset)
+    sd = copy.deepcopy(small_scene(demo2, 48, 36))
+    mesh = heightfield_mesh(40, 30, seed=3)
+    mesh.vertices = mesh.vertices * np.array([0.05, 1.0, 0.05]) + off   # ~1.4 x 0.7 x 1.5 in extent, far away
+    moved = []
+    for s in sd.shapes:
+        s = copy.deepcopy(s)
+        if isinstance(s, SphereData):
+            s.center = tuple(np.array(s.center) * (0.05 if s.radius < 50 else 1.0) + off)
+            s.radius = s.radius * 0.05 if s.radius < 50 else s.radius
+        elif isinstance(s, PlaneData):
+            s.point = tuple(np.array(s.point) + off - np.array([0.0, 1.0, 0.0]))
+        moved.append(s)
+    sd.shapes = moved + [mesh]
+    sd.camera_settings.eye = tuple(np.array([0.0, 1.6, -1.2]) + off)
+    sd.camera_settings.look_at = tuple(np.array([0.0, 0.0, 0.2]) + off)
+    rng = np.random.default_rng(9)
+    n = 4096
+    tgt = mesh.vertices[rng.integers(0, len(mesh.vertices), n)]
+    o = tgt + rng.normal(size=(n, 3)) * np.array([1.0, 0.3, 1.0]) + np.array([0.0, 0.8, 0.0])
+    d = tgt - o + rng.normal(size=(n, 3)) * 0.02
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    with flux.Renderer(sd, flux.JobConfiguration(8, 5, 50), seed=2) as r:
+        r.set_traversal(flux._lib.TRAVERSE_BVH)
+        _, hit_b, t_b = r.debug_shade(o, d, depth=5)
+        r.set_traversal(flux._lib.TRAVERSE_BRUTE)
+        _, hit_f, t_f = r.debug_shade(o, d, depth=5)
+        assert np.array_equal(hit_b, hit_f)
+        assert (hit_f >= len(moved)).sum() > n // 3                     # a good share of first hits ARE triangles
+        assert np.abs(t_b - t_f).max() <= 1e-12 * max(1.0, np.abs(t_f).max())
+        r.enable_stats(True)
+        out = {}
+        for trav in (flux._lib.TRAVERSE_BVH, flux._lib.TRAVERSE_BRUTE):
+            r.set_traversal(trav)
+            r.stats(reset=True)
+            img = r.render_frame()                                      # 64 spp: the state machine over DevNodeQ
+            st = r.stats(reset=True)
+            out[trav] = (img, {k: v for k, v in st.items() if k not in ("bvh_nodes", "tris_tested")})
+        assert out[flux._lib.TRAVERSE_BVH][1] == out[flux._lib.TRAVERSE_BRUTE][1]
+        assert max_abs_diff(out[flux._lib.TRAVERSE_BVH][0], out[flux._lib.TRAVERSE_BRUTE][0]) < 1e-12
+
+
+@pytest.mark.gpu
 def test_bvh_stats_and_degenerate_meshes(flux, oracle_mod, demo2):
     from flux_amd.procedural import heightfield_scene
     from flux_amd.scene import MeshData
