@@ -20,6 +20,10 @@
 #ifndef FLUX_UNI_SPHERES
 #define FLUX_UNI_SPHERES 2
 #endif
+// FAST: reproduce BoundingBox::hit's z-slab NaN miss (render_body.inc box_z_nan_miss); 0 only for A/B experiments
+#ifndef FLUX_Z_SLAB_RULE
+#define FLUX_Z_SLAB_RULE 1
+#endif
 #ifndef FLUX_SET_GROUPED
 #define FLUX_SET_GROUPED 1
 #endif
