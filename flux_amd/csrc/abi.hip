@@ -73,6 +73,8 @@ struct flux_ctx {
     // extension: triangle meshes
     flux::DevTri *d_tris = nullptr;
     flux::DevNode *d_nodes = nullptr;
+    flux::DevNode4Q *d_nodes4 = nullptr;
+    flux::DevLeafRec *d_leaves = nullptr;
     flux::DevNodeQ *d_nodesq = nullptr;
     flux::BvhInfo bvh{};
     int traversal = FLUX_TRAVERSE_BVH;
@@ -117,6 +119,8 @@ static void free_ctx(flux_ctx *c) {
     (void)hipFree(c->d_tris);
     (void)hipFree(c->d_nodes);
     (void)hipFree(c->d_nodesq);
+    (void)hipFree(c->d_nodes4);
+    (void)hipFree(c->d_leaves);
     (void)hipFree(c->d_out);
     delete c;
 }
@@ -391,6 +395,16 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         delete c;
         return code;
     }
+    // the FAST traversal kernel's layout: 4-wide nodes + leaf records (flux_bvh.h)
+    std::vector<flux::DevNode4Q> nodes4;
+    std::vector<flux::DevLeafRec> leafrecs;
+    flux::build_wide(nodes, nodesq, tris, nodes4, leafrecs, c->bvh);
+    if (nodes4.size() * sizeof(flux::DevNode4Q) >= (1ull << 32) || leafrecs.size() * sizeof(flux::DevLeafRec) >= (1ull << 32) ||
+        leafrecs.size() >= (1ull << 28)) {
+        int code = fail(FLUX_E_INVALID, "mesh too large for the traversal kernel's 32-bit record offsets");
+        delete c;
+        return code;
+    }
     if (c->bvh.max_depth > (uint64_t)flux::kBvhMaxDepth) {
         int code = fail(FLUX_E_INVALID, "BVH depth %llu exceeds %d (degenerate mesh)",
                         (unsigned long long)c->bvh.max_depth, flux::kBvhMaxDepth);
@@ -465,6 +479,11 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         if (e == hipSuccess) e = hipMemcpy(c->d_nodes, nodes.data(), nodes.size() * sizeof(flux::DevNode), hipMemcpyHostToDevice);
         alloc((void **)&c->d_nodesq, nodesq.size() * sizeof(flux::DevNodeQ));
         if (e == hipSuccess) e = hipMemcpy(c->d_nodesq, nodesq.data(), nodesq.size() * sizeof(flux::DevNodeQ), hipMemcpyHostToDevice);
+        alloc((void **)&c->d_nodes4, nodes4.size() * sizeof(flux::DevNode4Q));
+        if (e == hipSuccess) e = hipMemcpy(c->d_nodes4, nodes4.data(), nodes4.size() * sizeof(flux::DevNode4Q), hipMemcpyHostToDevice);
+        alloc((void **)&c->d_leaves, (leafrecs.size() + 1) * sizeof(flux::DevLeafRec));
+        if (e == hipSuccess && !leafrecs.empty())
+            e = hipMemcpy(c->d_leaves, leafrecs.data(), leafrecs.size() * sizeof(flux::DevLeafRec), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMemcpy(c->d_shapes, shapes.data(), shapes.size() * sizeof(flux::DevShape), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_mats, mats.data(), mats.size() * sizeof(flux::DevMaterial), hipMemcpyHostToDevice);
@@ -499,6 +518,10 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.n_tris = (int32_t)tris.size();
     rp.bvh_stack = (int32_t)c->bvh.max_depth;
     rp.nodesq = c->d_nodesq;
+    rp.nodes4 = c->d_nodes4;
+    rp.leaves = c->d_leaves;
+    rp.bvh4_stack = (int32_t)c->bvh.wide_stack;
+    rp.pad_bvh4 = 0;
     for (int a = 0; a < 3; a++) {
         rp.bvh_qmin[a] = c->bvh.qmin[a];
         rp.bvh_qstep[a] = c->bvh.qstep[a];
@@ -777,7 +800,7 @@ int flux_ctx_set_traversal(flux_ctx *ctx, int mode) {
     return FLUX_OK;
 }
 
-int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t out[8]) {
+int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t out[FLUX_BVH_INFO_WORDS]) {
     if (!ctx || !out) return fail(FLUX_E_INVALID, "null argument");
     out[0] = ctx->bvh.nodes;
     out[1] = ctx->bvh.tris;
@@ -786,7 +809,13 @@ int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t out[8]) {
     out[4] = sizeof(flux::DevNode);
     out[5] = sizeof(flux::DevTri);
     out[6] = ctx->bvh.build_us;
-    out[7] = 0;
+    out[7] = ctx->bvh.wide_nodes;
+    out[8] = ctx->bvh.leaf_records;
+    out[9] = ctx->bvh.fused_leaves;
+    out[10] = ctx->bvh.wide_stack;
+    out[11] = sizeof(flux::DevNode4Q);
+    out[12] = sizeof(flux::DevLeafRec);
+    out[13] = out[14] = out[15] = 0;
     return FLUX_OK;
 }
 

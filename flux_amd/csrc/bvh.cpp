@@ -7,6 +7,7 @@
 #include "flux_bvh.h"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -357,6 +358,155 @@ bool quantize_bvh(const std::vector<DevNode> &nodes, std::vector<DevNodeQ> &out,
         }
     }
     return true;
+}
+
+void build_wide(const std::vector<DevNode> &nodes, const std::vector<DevNodeQ> &nodesq, const std::vector<DevTri> &tris,
+                std::vector<DevNode4Q> &wide, std::vector<DevLeafRec> &leaves, BvhInfo &info) {
+    wide.clear();
+    leaves.clear();
+    info.wide_nodes = info.leaf_records = info.fused_leaves = info.wide_stack = 0;
+    if (nodes.empty()) return;
+    struct Slot {
+        int32_t link;        // binary link: >= 0 inner node, < 0 leaf reference
+        uint16_t lo[3], hi[3];
+        float area;
+    };
+    auto slot_of = [&](int32_t parent, int side) {
+        const DevNode &N = nodes[(size_t)parent];
+        const DevNodeQ &Q = nodesq[(size_t)parent];
+        Slot s;
+        s.link = side ? N.child1 : N.child0;
+        const float *lo = side ? N.lo1 : N.lo0, *hi = side ? N.hi1 : N.hi0;
+        for (int a = 0; a < 3; a++) {
+            s.lo[a] = side ? Q.lo1[a] : Q.lo0[a];
+            s.hi[a] = side ? Q.hi1[a] : Q.hi0[a];
+        }
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        s.area = (dx >= 0 && dy >= 0 && dz >= 0) ? 2.0f * (dx * dy + dy * dz + dz * dx) : -1.0f;
+        return s;
+    };
+    // leaf reference of the binary tree -> records (a fused pair where the two triangles are the halves of a quad)
+    auto leaf_ref = [&](int32_t link) -> int32_t {
+        const int ref = ~link;
+        const int first = ref >> 3, cnt = ref & 7;
+        const size_t rec_first = leaves.size();
+        auto single = [&](int k) {
+            const DevTri &T = tris[(size_t)k];
+            DevLeafRec R;
+            std::memset(&R, 0, sizeof(R));
+            R.v0[0] = T.v0x; R.v0[1] = T.v0y; R.v0[2] = T.v0z;
+            R.e1[0] = T.e1x; R.e1[1] = T.e1y; R.e1[2] = T.e1z;
+            R.e2[0] = T.e2x; R.e2[1] = T.e2y; R.e2[2] = T.e2z;
+            R.id[0] = T.id; R.id[1] = -1;
+            R.slot[0] = k; R.slot[1] = -1;
+            leaves.push_back(R);
+        };
+        auto same3 = [](double ax, double ay, double az, double bx, double by, double bz) { return ax == bx && ay == by && az == bz; };
+        int k = 0;
+        while (k < cnt) {
+            bool fused = false;
+            if (k + 1 < cnt) {
+                const DevTri &A = tris[(size_t)(first + k)], &B = tris[(size_t)(first + k + 1)];
+                if (same3(A.v0x, A.v0y, A.v0z, B.v0x, B.v0y, B.v0z)) {
+                    const DevTri *X = nullptr, *Y = nullptr;  // X = (v0, e1, e2), Y = (v0, e2, e3)
+                    int sx = 0, sy = 0;
+                    if (same3(A.e2x, A.e2y, A.e2z, B.e1x, B.e1y, B.e1z)) { X = &A; Y = &B; sx = first + k; sy = first + k + 1; }
+                    else if (same3(B.e2x, B.e2y, B.e2z, A.e1x, A.e1y, A.e1z)) { X = &B; Y = &A; sx = first + k + 1; sy = first + k; }
+                    if (X) {
+                        DevLeafRec R;
+                        std::memset(&R, 0, sizeof(R));
+                        R.v0[0] = X->v0x; R.v0[1] = X->v0y; R.v0[2] = X->v0z;
+                        R.e1[0] = X->e1x; R.e1[1] = X->e1y; R.e1[2] = X->e1z;
+                        R.e2[0] = X->e2x; R.e2[1] = X->e2y; R.e2[2] = X->e2z;
+                        R.e3[0] = Y->e2x; R.e3[1] = Y->e2y; R.e3[2] = Y->e2z;
+                        R.id[0] = X->id; R.id[1] = Y->id;
+                        R.slot[0] = sx; R.slot[1] = sy;
+                        leaves.push_back(R);
+                        info.fused_leaves++;
+                        fused = true;
+                        k += 2;
+                    }
+                }
+            }
+            if (!fused) {
+                single(first + k);
+                k++;
+            }
+        }
+        const size_t nrec = leaves.size() - rec_first;  // <= cnt <= 7
+        return ~(int32_t)(((uint32_t)rec_first << 3) | (uint32_t)nrec);
+    };
+    // breadth-first over the binary nodes that survive as 4-wide nodes
+    std::vector<int32_t> queue;      // binary index of wide node k
+    std::vector<int32_t> wide_of(nodes.size(), -1);
+    queue.push_back(0);
+    wide_of[0] = 0;
+    std::vector<std::array<Slot, 4>> slots_of;
+    std::vector<int> count_of;
+    for (size_t head = 0; head < queue.size(); head++) {
+        const int32_t b = queue[head];
+        Slot sl[4];
+        int n = 2;
+        sl[0] = slot_of(b, 0);
+        sl[1] = slot_of(b, 1);
+        while (n < 4) {  // open the inner child with the largest surface
+            int pick = -1;
+            for (int k = 0; k < n; k++)
+                if (sl[k].link >= 0 && (pick < 0 || sl[k].area > sl[pick].area)) pick = k;
+            if (pick < 0) break;
+            const int32_t c = sl[pick].link;
+            sl[pick] = slot_of(c, 0);
+            sl[n++] = slot_of(c, 1);
+        }
+        std::array<Slot, 4> arr;
+        for (int k = 0; k < 4; k++) arr[(size_t)k] = sl[k < n ? k : 0];
+        slots_of.push_back(arr);
+        count_of.push_back(n);
+        for (int k = 0; k < n; k++)
+            if (sl[k].link >= 0) {
+                wide_of[(size_t)sl[k].link] = (int32_t)queue.size();
+                queue.push_back(sl[k].link);
+            }
+    }
+    wide.resize(queue.size());
+    for (size_t w = 0; w < queue.size(); w++) {
+        DevNode4Q &W = wide[w];
+        const int n = count_of[w];
+        for (int k = 0; k < 4; k++) {
+            if (k < n) {
+                const Slot &S = slots_of[w][(size_t)k];
+                W.bx[k] = (uint32_t)S.lo[0] | ((uint32_t)S.hi[0] << 16);
+                W.by[k] = (uint32_t)S.lo[1] | ((uint32_t)S.hi[1] << 16);
+                W.bz[k] = (uint32_t)S.lo[2] | ((uint32_t)S.hi[2] << 16);
+                // an empty leaf of the binary tree (the one-leaf tree's second slot: count 0) stays an empty slot
+                if (S.link < 0 && ((~S.link) & 7) == 0) {
+                    W.bx[k] = W.by[k] = W.bz[k] = 0x0000ffffu;
+                    W.link[k] = (int32_t)0x80000000;
+                } else {
+                    W.link[k] = S.link >= 0 ? wide_of[(size_t)S.link] : leaf_ref(S.link);
+                }
+            } else {
+                W.bx[k] = W.by[k] = W.bz[k] = 0x0000ffffu;  // lo 65535, hi 0: never hit
+                W.link[k] = (int32_t)0x80000000;
+            }
+        }
+    }
+    // most stack entries at once: a visit of a node with k children leaves at most k - 1 behind
+    std::vector<uint32_t> need(wide.size(), 0);
+    for (size_t w = wide.size(); w-- > 0;) {  // children have larger indices (breadth-first): bottom-up
+        const DevNode4Q &W = wide[w];
+        int kids = 0;
+        uint32_t deepest = 0;
+        for (int k = 0; k < 4; k++) {
+            if (W.link[k] == (int32_t)0x80000000) continue;
+            kids++;
+            if (W.link[k] >= 0) deepest = std::max(deepest, need[(size_t)W.link[k]]);
+        }
+        need[w] = (uint32_t)(kids > 0 ? kids - 1 : 0) + deepest;
+    }
+    info.wide_nodes = wide.size();
+    info.leaf_records = leaves.size();
+    info.wide_stack = need[0];
 }
 
 }  // namespace flux

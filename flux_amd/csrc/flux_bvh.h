@@ -44,6 +44,29 @@ struct DevNodeQ {
 };
 static_assert(sizeof(DevNodeQ) == 32, "DevNodeQ layout");
 
+// ---- the FAST traversal kernel's own layout (round 3) -------------------------------------------------------------------
+// Measured (scripts/micro/gather_rate.hip, profiles/r03_experiments): a divergent gather costs the CU's vector-memory
+// pipeline per ACTIVE LANE and per 128-B LINE it has to fill -- ~2.4 cycles per lane-line served by the L2, ~9 when the
+// line comes from beyond it -- while further 16-B pieces of the SAME line cost ~0.4.  The state machine is bound by exactly
+// that, so the layout minimises LINES per ray segment:
+//   * 4-wide nodes of 64 B (two per line, never straddling): the binary SAH tree collapsed by surface area, child boxes on
+//     the same 16-bit grid as DevNodeQ -- half the visits of the binary tree, one line each;
+//   * leaf records of 128 B that hold TWO triangles when they share v0 and an edge (tri A = v0,e1,e2; tri B = v0,e2,e3:
+//     the two halves of a quad, as every leaf of a triangulated grid is) -- one line instead of two, the same operands
+//     bit for bit as the DevTri records, so the exact f64 test is unchanged.
+struct DevNode4Q {
+    uint32_t bx[4], by[4], bz[4];  // per child and axis: lo | hi << 16 on the grid (an empty slot: lo 65535, hi 0)
+    int32_t link[4];               // >= 0: DevNode4Q index; < 0: ~((first_record << 3) | records), 0x80000000 = empty slot
+};
+static_assert(sizeof(DevNode4Q) == 64, "DevNode4Q layout");
+struct DevLeafRec {
+    double v0[3], e1[3], e2[3], e3[3];  // triangle A = (v0, e1, e2), triangle B = (v0, e2, e3)
+    int32_t id[2];                      // hit-order indices (DevTri::id)
+    int32_t slot[2];                    // DevTri indices (normal + material at shading time); slot[1] < 0: no triangle B
+    double pad[2];
+};
+static_assert(sizeof(DevLeafRec) == 128, "DevLeafRec layout");
+
 constexpr int kBvhSahDepth = 32;    // below this depth the builder uses SAH, deeper: median splits
 constexpr int kBvhMaxDepth = 64;    // hard limit; the per-lane LDS stack is sized max_depth entries
 #ifndef FLUX_BVH_LEAF
@@ -55,6 +78,8 @@ struct BvhInfo {
     uint64_t nodes = 0, tris = 0, max_depth = 0, max_leaf = 0, build_us = 0;
     double mag = 0.0;  // largest |coordinate| of any vertex (scale of the f32 slab test's padding)
     float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};  // the 16-bit grid of DevNodeQ: coordinate = qmin + q * qstep
+    uint64_t wide_nodes = 0, leaf_records = 0, fused_leaves = 0;
+    uint64_t wide_stack = 0;  // most entries the 4-wide traversal can have stacked at once (sum of children - 1 along a path)
 };
 
 // Binned-SAH top-down build.  `tris` is reordered into leaf order (ids keep the original order).
@@ -63,5 +88,9 @@ void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &
 // `nodes` on the 16-bit grid (fills info.qmin / qstep).  Every quantised box CONTAINS the f32 box it comes from; the
 // function verifies that and returns false if it does not hold (the caller refuses the mesh).
 bool quantize_bvh(const std::vector<DevNode> &nodes, std::vector<DevNodeQ> &out, BvhInfo &info);
+
+// The 4-wide tree + leaf records of the FAST traversal kernel from the binary tree and its quantised boxes.
+void build_wide(const std::vector<DevNode> &nodes, const std::vector<DevNodeQ> &nodesq, const std::vector<DevTri> &tris,
+                std::vector<DevNode4Q> &wide, std::vector<DevLeafRec> &leaves, BvhInfo &info);
 
 }  // namespace flux

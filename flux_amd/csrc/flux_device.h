@@ -181,6 +181,10 @@ struct RenderParams {
     const DevNode *nodes;  // node 0 = root
     const DevNodeQ *nodesq;  // the same nodes, 32 B each, boxes on a 16-bit grid (FAST traversal state machine)
     float bvh_qmin[3], bvh_qstep[3];  // that grid: coordinate = qmin + q * qstep
+    const DevNode4Q *nodes4;   // the 4-wide tree of the FAST traversal kernel (flux_bvh.h), or nullptr
+    const DevLeafRec *leaves;  // its leaf records
+    int32_t bvh4_stack;        // most entries its per-lane stack can hold at once
+    int32_t pad_bvh4;
     int32_t n_tris;
     int32_t bvh_stack;     // per-lane traversal stack entries (= BVH max depth); 0 = brute force
     // FAST path scene (same shapes as `shapes`/`mats`)

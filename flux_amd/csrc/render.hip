@@ -50,6 +50,9 @@
 #ifndef FLUX_WPE_BVH
 #define FLUX_WPE_BVH 5            // waves/SIMD of the BVH traversal kernel
 #endif
+#ifndef FLUX_BVH_WIDE
+#define FLUX_BVH_WIDE 1           // FAST mesh scenes: render_bvh4_kernel over the 4-wide tree (0: render_bvh_kernel over the binary one)
+#endif
 #ifndef FLUX_BVH_REFILL_AT
 #define FLUX_BVH_REFILL_AT 40     // lanes that must be waiting for shading before the wave leaves traversal (swept 16..64 with the leaf vote)
 #endif

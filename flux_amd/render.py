@@ -139,9 +139,10 @@ class Renderer:
         _lib.check(_lib.lib.flux_ctx_set_traversal(self._handle(), mode))
 
     def bvh_info(self) -> dict:
-        buf = (C.c_uint64 * 8)()
+        buf = (C.c_uint64 * 16)()
         _lib.check(_lib.lib.flux_ctx_bvh_info(self._handle(), buf))
-        names = ("nodes", "triangles", "max_depth", "max_leaf", "node_bytes", "tri_bytes", "build_us")
+        names = ("nodes", "triangles", "max_depth", "max_leaf", "node_bytes", "tri_bytes", "build_us", "wide_nodes",
+                 "leaf_records", "fused_leaves", "wide_stack", "wide_node_bytes", "leaf_record_bytes")
         return dict(zip(names, [int(x) for x in buf]))
 
     def table(self, which: int) -> np.ndarray:

@@ -230,9 +230,12 @@ double flux_ctx_last_kernel_ms(flux_ctx *ctx);
 int flux_ctx_enable_stats(flux_ctx *ctx, int on);
 int flux_ctx_stats(flux_ctx *ctx, uint64_t out[FLUX_NUM_STATS], int reset);
 
-/* BVH introspection (extension): out[0] nodes, [1] triangles, [2] max depth, [3] max leaf size,
- * [4] node bytes, [5] triangle-record bytes, [6] build microseconds, [7] reserved. */
-int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t out[8]);
+/* BVH introspection (extension): out[0] nodes of the binary tree, [1] triangles, [2] its max depth, [3] max leaf size,
+ * [4] its node bytes, [5] triangle-record bytes, [6] build microseconds; the 4-wide tree the FAST traversal kernel walks:
+ * [7] nodes, [8] leaf records, [9] of them holding two triangles (the halves of a quad), [10] most stack entries at once,
+ * [11] node bytes, [12] leaf-record bytes; [13..15] reserved (0). */
+#define FLUX_BVH_INFO_WORDS 16
+int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t out[FLUX_BVH_INFO_WORDS]);
 
 /* Introspection used by the parity tests (device -> host copies).
  * which: 0 = pixel_sets [S][N][2], 1 = disc_sets [S][N][2],
