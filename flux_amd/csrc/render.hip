@@ -53,6 +53,15 @@
 #ifndef FLUX_BVH_WIDE
 #define FLUX_BVH_WIDE 1           // FAST mesh scenes: render_bvh4_kernel over the 4-wide tree (0: render_bvh_kernel over the binary one)
 #endif
+#ifndef FLUX_BVH4_PERM
+#define FLUX_BVH4_PERM 1          // render_bvh4_kernel's slab test: v_perm + magic-number planes + v_pk_fma_f32 (0: rotate + convert)
+#endif
+#ifndef FLUX_BVH4_SORT
+#define FLUX_BVH4_SORT 0          // render_bvh4_kernel: 1 = hit children fully sorted by entry distance; 0 = only the nearest is singled
+#endif                            //   out and the others stacked as they come (1024 spp: 165.7 -> 159.6 ms; 0.6 % more node visits)
+#ifndef FLUX_WPE_BVH4
+#define FLUX_WPE_BVH4 4           // waves/SIMD of render_bvh4_kernel: 122 VGPRs, no scratch (at 5: 96 VGPRs, 48 spilled, 180 vs 160 ms)
+#endif
 #ifndef FLUX_BVH_REFILL_AT
 #define FLUX_BVH_REFILL_AT 40     // lanes that must be waiting for shading before the wave leaves traversal (swept 16..64 with the leaf vote)
 #endif
