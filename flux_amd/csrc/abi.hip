@@ -545,7 +545,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.n_uni = n_uni;
     rp.uni_idx[0] = uni_idx[0];
     rp.uni_idx[1] = uni_idx[1];
-    rp.pad_uni = 0;
+    rp.unit_dirs = rp.glossy_long ? 0 : 1;
     rp.self_skip = (FLUX_SELF_SKIP && !rp.glossy_long) ? 1 : 0;
     for (const flux::DevScanSphere &sp : fsph)
         if (!(std::fabs(sp.px) < 1e3 && std::fabs(sp.py) < 1e3 && std::fabs(sp.pz) < 1e3 && sp.rr < 1e6)) rp.self_skip = 0;
@@ -615,6 +615,7 @@ int flux_debug_shade(flux_ctx *ctx, uint64_t n, const double *rays, uint64_t dep
     flux::RenderParams p = ctx->rp;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
     p.glossy_long = 1;  // caller-supplied directions need not be unit vectors
+    p.unit_dirs = 0;
     p.self_skip = 0;
     if (int rc = check_lds_budget_rays(ctx, p)) {
         (void)hipFree(d_rays);

@@ -24,6 +24,10 @@
 #ifndef FLUX_Z_SLAB_RULE
 #define FLUX_Z_SLAB_RULE 1
 #endif
+// FAST scan: 1 = directions are taken as unit vectors where the scene guarantees it (RenderParams::unit_dirs)
+#ifndef FLUX_UNIT_DIRS
+#define FLUX_UNIT_DIRS 1
+#endif
 #ifndef FLUX_SET_GROUPED
 #define FLUX_SET_GROUPED 1
 #endif
@@ -209,7 +213,10 @@ struct RenderParams {
     int32_t self_skip;
     // FAST with the f32 filter: hit-record indices of up to two `invert` spheres that scan_shapes_fast tests for all
     // lanes together (their filter records never pass)
-    int32_t n_uni, uni_idx[2], pad_uni;
+    int32_t n_uni, uni_idx[2];
+    // FAST: 1 = no plane is stored with a non-unit normal (= !glossy_long) and the rays are the render loop's own: every
+    // ray direction is then a unit vector to rounding and scan_shapes_fast skips its normalisation
+    int32_t unit_dirs;
 };
 
 }  // namespace flux
