@@ -305,7 +305,15 @@ def main():
         # and triangles tested at their laid-out sizes (64 B / 128 B).  (As laid out here a glossy bounce also reads 24 B
         # of tabulated lobe factors: reported beside it, not counted in `achieved`.)
         table_bytes = 32.0 + 24.0 * mbar
-        bvh_bytes = (tot_nodes * bvh["node_bytes"] + tot_tris * bvh["tri_bytes"]) / tot_samples
+        # as laid out for the kernel that ran: 64-B 4-wide nodes and 128-B leaf records holding one or two triangles (counted
+        # per triangle test at 64 B when the record is a quad's) for render_bvh4_kernel; 32-B nodes (two 16-B gathers of a
+        # DevNodeQ) + 80 B of a DevTri for the binary-tree kernel; the inline walk of the other kernels reads DevNode / DevTri
+        wide = bool(bvh.get("wide_in_use")) and a.math == "fast" and n * n >= 64 and a.kernel != 1
+        if wide:
+            tri_b = bvh["leaf_record_bytes"] * bvh["leaf_records"] / max(bvh["triangles"], 1)
+            bvh_bytes = (tot_nodes * bvh["wide_node_bytes"] + tot_tris * tri_b) / tot_samples
+        else:
+            bvh_bytes = (tot_nodes * bvh["node_bytes"] + tot_tris * bvh["tri_bytes"]) / tot_samples
         bytes_per_sample = table_bytes + bvh_bytes
         # the dominant kernel's launch on rank 0 covers samples/world camera paths + its share of the framebuffer
         samples_launch = samples / world
@@ -314,7 +322,7 @@ def main():
         workload = f"{scene_label} {W}x{H} at {n * n} spp (sample_root {n}), depth {a.depth}, seed {a.seed}"
         dyn = n * n >= 64 and a.kernel != 1
         if dyn and a.math == "fast" and bvh["triangles"] > 0:
-            kernel_name = "render_bvh_kernel"
+            kernel_name = "render_bvh4_kernel" if bvh.get("wide_in_use") else "render_bvh_kernel"
         elif dyn and a.math == "fast" and a.kernel in (0, 3) and n * n >= (256 if a.kernel == 0 else 64) and bvh["triangles"] == 0:
             kernel_name = "render_split_kernel"
         else:

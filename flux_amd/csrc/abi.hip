@@ -816,7 +816,9 @@ int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t out[FLUX_BVH_INFO_WORDS]) {
     out[10] = ctx->bvh.wide_stack;
     out[11] = sizeof(flux::DevNode4Q);
     out[12] = sizeof(flux::DevLeafRec);
-    out[13] = out[14] = out[15] = 0;
+    // [13]: 1 = FAST mesh renders of >= 64 spp walk the 4-wide tree (render_bvh4_kernel), 0 = the binary one (render_bvh_kernel)
+    out[13] = (FLUX_BVH_WIDE && ctx->d_nodes4 != nullptr && ctx->bvh.wide_stack <= FLUX_BVH_WIDE_MAX_STACK) ? 1 : 0;
+    out[14] = out[15] = 0;
     return FLUX_OK;
 }
 

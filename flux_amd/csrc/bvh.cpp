@@ -13,6 +13,10 @@
 #include <cstring>
 #include <limits>
 
+#ifndef FLUX_BVH_COLLAPSE_MODE
+#define FLUX_BVH_COLLAPSE_MODE 0
+#endif
+
 namespace flux {
 namespace {
 
@@ -436,6 +440,12 @@ void build_wide(const std::vector<DevNode> &nodes, const std::vector<DevNodeQ> &
         const size_t nrec = leaves.size() - rec_first;  // <= cnt <= 7
         return ~(int32_t)(((uint32_t)rec_first << 3) | (uint32_t)nrec);
     };
+    // leaves below every binary node (children have larger indices after the breadth-first relabelling: bottom-up pass)
+    std::vector<uint32_t> leaves_below(nodes.size(), 0);
+    for (size_t k = nodes.size(); k-- > 0;) {
+        const DevNode &N = nodes[k];
+        leaves_below[k] = (N.child0 >= 0 ? leaves_below[(size_t)N.child0] : 1u) + (N.child1 >= 0 ? leaves_below[(size_t)N.child1] : 1u);
+    }
     // breadth-first over the binary nodes that survive as 4-wide nodes
     std::vector<int32_t> queue;      // binary index of wide node k
     std::vector<int32_t> wide_of(nodes.size(), -1);
@@ -451,8 +461,23 @@ void build_wide(const std::vector<DevNode> &nodes, const std::vector<DevNodeQ> &
         sl[1] = slot_of(b, 1);
         while (n < 4) {  // open the inner child with the largest surface
             int pick = -1;
-            for (int k = 0; k < n; k++)
-                if (sl[k].link >= 0 && (pick < 0 || sl[k].area > sl[pick].area)) pick = k;
+#if FLUX_BVH_COLLAPSE_MODE == 2
+            // a subtree of at most four leaves becomes ONE node: open whatever inner child is left
+            if (leaves_below[(size_t)b] <= 4)
+                for (int k = 0; k < n; k++)
+                    if (sl[k].link >= 0) pick = k;
+#endif
+#if FLUX_BVH_COLLAPSE_MODE >= 1
+            // ... but with the LAST free slot rather absorb a child whose own children are both leaves (a whole node less to visit)
+            if (n == 3)
+                for (int k = 0; k < n; k++)
+                    if (sl[k].link >= 0 && nodes[(size_t)sl[k].link].child0 < 0 && nodes[(size_t)sl[k].link].child1 < 0 &&
+                        (pick < 0 || sl[k].area > sl[pick].area))
+                        pick = k;
+#endif
+            if (pick < 0)
+                for (int k = 0; k < n; k++)
+                    if (sl[k].link >= 0 && (pick < 0 || sl[k].area > sl[pick].area)) pick = k;
             if (pick < 0) break;
             const int32_t c = sl[pick].link;
             sl[pick] = slot_of(c, 0);

@@ -28,6 +28,14 @@
 #ifndef FLUX_UNIT_DIRS
 #define FLUX_UNIT_DIRS 1
 #endif
+// FAST mesh scenes: 1 = render_bvh4_kernel over the 4-wide tree (flux_bvh.h), 0 = render_bvh_kernel over the binary one
+#ifndef FLUX_BVH_WIDE
+#define FLUX_BVH_WIDE 1
+#endif
+// ... as long as its per-lane stack needs at most this many entries (48 x 256 B = 12 KiB of LDS per wave: 3 waves/SIMD)
+#ifndef FLUX_BVH_WIDE_MAX_STACK
+#define FLUX_BVH_WIDE_MAX_STACK 48
+#endif
 #ifndef FLUX_SET_GROUPED
 #define FLUX_SET_GROUPED 1
 #endif

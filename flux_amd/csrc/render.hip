@@ -50,9 +50,6 @@
 #ifndef FLUX_WPE_BVH
 #define FLUX_WPE_BVH 5            // waves/SIMD of the BVH traversal kernel
 #endif
-#ifndef FLUX_BVH_WIDE
-#define FLUX_BVH_WIDE 1           // FAST mesh scenes: render_bvh4_kernel over the 4-wide tree (0: render_bvh_kernel over the binary one)
-#endif
 #ifndef FLUX_BVH4_PERM
 #define FLUX_BVH4_PERM 1          // render_bvh4_kernel's slab test: v_perm + magic-number planes + v_pk_fma_f32 (0: rotate + convert)
 #endif

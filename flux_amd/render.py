@@ -142,7 +142,7 @@ class Renderer:
         buf = (C.c_uint64 * 16)()
         _lib.check(_lib.lib.flux_ctx_bvh_info(self._handle(), buf))
         names = ("nodes", "triangles", "max_depth", "max_leaf", "node_bytes", "tri_bytes", "build_us", "wide_nodes",
-                 "leaf_records", "fused_leaves", "wide_stack", "wide_node_bytes", "leaf_record_bytes")
+                 "leaf_records", "fused_leaves", "wide_stack", "wide_node_bytes", "leaf_record_bytes", "wide_in_use")
         return dict(zip(names, [int(x) for x in buf]))
 
     def table(self, which: int) -> np.ndarray:

@@ -233,7 +233,7 @@ int flux_ctx_stats(flux_ctx *ctx, uint64_t out[FLUX_NUM_STATS], int reset);
 /* BVH introspection (extension): out[0] nodes of the binary tree, [1] triangles, [2] its max depth, [3] max leaf size,
  * [4] its node bytes, [5] triangle-record bytes, [6] build microseconds; the 4-wide tree the FAST traversal kernel walks:
  * [7] nodes, [8] leaf records, [9] of them holding two triangles (the halves of a quad), [10] most stack entries at once,
- * [11] node bytes, [12] leaf-record bytes; [13..15] reserved (0). */
+ * [11] node bytes, [12] leaf-record bytes, [13] 1 if FAST renders walk the 4-wide tree (0: the binary one); [14..15] reserved (0). */
 #define FLUX_BVH_INFO_WORDS 16
 int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t out[FLUX_BVH_INFO_WORDS]);
 
