@@ -19,7 +19,7 @@ KERNEL_DEFAULT, KERNEL_STATIC, KERNEL_REFILL, KERNEL_SPLIT = 0, 1, 2, 3
 MATH_FAST, MATH_STRICT = 0, 1
 SAMPLER_REGULAR, SAMPLER_JITTERED, SAMPLER_MULTI_JITTERED, SAMPLER_CORRELATED_MULTI_JITTERED = 0, 1, 2, 3
 TABLE_PIXEL, TABLE_DISC, TABLE_HEMI = 0, 1, 2
-TRAVERSE_BVH, TRAVERSE_BRUTE = 0, 1
+TRAVERSE_BVH, TRAVERSE_BRUTE, TRAVERSE_BVH_BINARY = 0, 1, 2
 NUM_STATS = 16
 
 

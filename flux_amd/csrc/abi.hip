@@ -614,6 +614,7 @@ int flux_debug_shade(flux_ctx *ctx, uint64_t n, const double *rays, uint64_t dep
     if (e == hipSuccess) e = hipMemcpy(d_rays, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice);
     flux::RenderParams p = ctx->rp;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
+    if (ctx->traversal == FLUX_TRAVERSE_BVH_BINARY) p.nodes4 = nullptr;
     p.glossy_long = 1;  // caller-supplied directions need not be unit vectors
     p.unit_dirs = 0;
     p.self_skip = 0;
@@ -707,6 +708,7 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
     p.num_rows = (int32_t)num_rows;
     p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
+    if (ctx->traversal == FLUX_TRAVERSE_BVH_BINARY) p.nodes4 = nullptr;
     if (int rc = check_lds_budget(ctx, p, "flux_render_rows")) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
@@ -747,6 +749,7 @@ int flux_render_sets_device(flux_ctx *ctx, uint64_t first_set, uint64_t set_stri
     p.slot_stride = (int32_t)(set_stride / ctx->sets.stride);
     p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
     if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
+    if (ctx->traversal == FLUX_TRAVERSE_BVH_BINARY) p.nodes4 = nullptr;
     if (int rc = check_lds_budget(ctx, p, "flux_render_sets_device")) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
@@ -795,7 +798,7 @@ int flux_ctx_enable_stats(flux_ctx *ctx, int on) {
 
 int flux_ctx_set_traversal(flux_ctx *ctx, int mode) {
     if (!ctx) return fail(FLUX_E_INVALID, "null context");
-    if (mode != FLUX_TRAVERSE_BVH && mode != FLUX_TRAVERSE_BRUTE)
+    if (mode != FLUX_TRAVERSE_BVH && mode != FLUX_TRAVERSE_BRUTE && mode != FLUX_TRAVERSE_BVH_BINARY)
         return fail(FLUX_E_INVALID, "unknown traversal mode %d", mode);
     ctx->traversal = mode;
     return FLUX_OK;
@@ -817,7 +820,8 @@ int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t out[FLUX_BVH_INFO_WORDS]) {
     out[11] = sizeof(flux::DevNode4Q);
     out[12] = sizeof(flux::DevLeafRec);
     // [13]: 1 = FAST mesh renders of >= 64 spp walk the 4-wide tree (render_bvh4_kernel), 0 = the binary one (render_bvh_kernel)
-    out[13] = (FLUX_BVH_WIDE && ctx->d_nodes4 != nullptr && ctx->bvh.wide_stack <= FLUX_BVH_WIDE_MAX_STACK) ? 1 : 0;
+    out[13] = (FLUX_BVH_WIDE && ctx->d_nodes4 != nullptr && ctx->bvh.wide_stack <= FLUX_BVH_WIDE_MAX_STACK &&
+               ctx->traversal == FLUX_TRAVERSE_BVH) ? 1 : 0;
     out[14] = out[15] = 0;
     return FLUX_OK;
 }

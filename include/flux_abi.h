@@ -214,6 +214,9 @@ int flux_ctx_set_math(flux_ctx *ctx, int mode);
  * all triangles in index order (the definition the BVH must reproduce exactly; parity tests). */
 #define FLUX_TRAVERSE_BVH 0
 #define FLUX_TRAVERSE_BRUTE 1
+/* the BVH, but the FAST state-machine kernel walks the BINARY tree (32-B nodes, one record per triangle: round 2's kernel,
+ * otherwise only the fallback for meshes whose 4-wide tree needs too deep a stack) -- a test hook that keeps it exercised */
+#define FLUX_TRAVERSE_BVH_BINARY 2
 int flux_ctx_set_traversal(flux_ctx *ctx, int mode);
 
 /* Device time (ms, HIP events on the launch stream) of the most recent render

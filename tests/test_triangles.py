@@ -183,6 +183,35 @@ def test_bvh_of_a_mesh_far_from_the_origin(flux, demo2, offset):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nx,nz,n", [(60, 40, 8), (7, 5, 11)])
+def test_wide_and_binary_state_machines_agree(flux, demo2, nx, nz, n):
+    """The FAST mesh kernel over the 4-wide tree with quad leaf records (render_bvh4_kernel, the default), the same state
+    machine over the binary tree (render_bvh_kernel: the fallback, selected here through FLUX_TRAVERSE_BVH_BINARY) and brute
+    force take the same decisions -- identical path statistics -- and give the same image up to the order in which a
+    pixel's samples are summed; the node / triangle-test counters show that the two trees really are different walks."""
+    from flux_amd.procedural import heightfield_scene
+    sd = heightfield_scene(nx, nz, seed=11, base=small_scene(demo2, 48, 36))
+    with flux.Renderer(sd, flux.JobConfiguration(n, 5, 50), seed=4) as r:
+        assert r.bvh_info()["wide_in_use"] == 1 and r.bvh_info()["leaf_records"] >= nx * nz
+        r.enable_stats(True)
+        out = {}
+        for name, trav in (("wide", flux._lib.TRAVERSE_BVH), ("binary", flux._lib.TRAVERSE_BVH_BINARY), ("brute", flux._lib.TRAVERSE_BRUTE)):
+            r.set_traversal(trav)
+            r.stats(reset=True)
+            img = r.render_frame()
+            st = r.stats(reset=True)
+            out[name] = (img, st)
+        r.set_traversal(flux._lib.TRAVERSE_BVH_BINARY)
+        assert r.bvh_info()["wide_in_use"] == 0
+    drop = ("bvh_nodes", "tris_tested")
+    core = {k: {a: b for a, b in v[1].items() if a not in drop} for k, v in out.items()}
+    assert core["wide"] == core["binary"] == core["brute"]
+    assert max_abs_diff(out["wide"][0], out["brute"][0]) < 1e-13 and max_abs_diff(out["binary"][0], out["brute"][0]) < 1e-13
+    assert 0 < out["wide"][1]["bvh_nodes"] < out["binary"][1]["bvh_nodes"]          # half as deep
+    assert out["brute"][1]["bvh_nodes"] == 0 and out["brute"][1]["tris_tested"] == out["brute"][1]["segments"] * 2 * nx * nz
+
+
+@pytest.mark.gpu
 def test_bvh_stats_and_degenerate_meshes(flux, oracle_mod, demo2):
     from flux_amd.procedural import heightfield_scene
     from flux_amd.scene import MeshData
