@@ -25,7 +25,9 @@
 //    (ballot + mbcnt prefix), so lanes stay busy although path lengths differ (1..D segments);
 //  * REFILL kernel (STRICT; 64..255 spp): the same refill discipline with primaries and secondaries mixed in one loop;
 //    STATIC kernel (< 64 spp): lane l traces samples l, l+64, ...;
-//  * BVH kernel (FAST mesh scenes): persistent lanes with a per-lane traversal state machine over 32-B quantised nodes;
+//  * BVH kernels (FAST mesh scenes): persistent lanes with a per-lane traversal state machine -- over a 4-wide tree of 64-B
+//    nodes (boxes on a 16-bit grid, planes built by v_perm_b32, tested through v_pk_fma_f32) with 128-B leaf records that
+//    hold both halves of a quad (render_bvh4_kernel), or over the binary tree of 32-B nodes (render_bvh_kernel, fallback);
 //  * per-lane partial sums are combined in lane order, wave totals in wave order (a fixed tree => the image is
 //    bit-reproducible run to run and independent of how the frame is split), then * 1/n^2, max_to_one, and the
 //    3 doubles are written once.  No atomics.
