@@ -115,37 +115,38 @@ def load_profile(scene_label, kernel_name):
     return None
 
 
-def rccl_probe(sh, dev):
-    """N = 1 only, after the timed region: bring up a world-size-1 NCCL (= RCCL) process group in THIS process and run the
-    frame's one collective, all_gather_into_tensor, on the sharder's own device buffers -- the part of the N > 1 path
-    (fluxcore/src/manager.rs:316-324's gather) that a single GPU can execute.  Never raises: the line reports what happened."""
+def rccl_probe(frame_bytes):
+    """N = 1 only, after the timed region: a FRESH child process (tests/rccl_child.py, the test's own child; never an exec
+    from this GPU-holding process) brings up a world-size-1 NCCL (= RCCL) group on this GPU, renders a small demo2 frame
+    through both sharders and runs the frame's one collective, all_gather_into_tensor, on their device buffers -- the part of
+    the N > 1 path (fluxcore/src/manager.rs:316-324's gather) a single GPU can execute.  Bounded by a timeout and never
+    raises: the line reports what happened."""
     import socket
-    import torch
-    import torch.distributed as dist
+    import subprocess
+    import tempfile
     rep = {"ran": False}
     try:
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("nccl", world_size=1, rank=0, device_id=dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        dist.all_gather_into_tensor(sh.gathered.view(-1), sh.local.view(-1))  # communicator creation happens here
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(10):
-            dist.all_gather_into_tensor(sh.gathered.view(-1), sh.local.view(-1))
-        e1.record()
-        torch.cuda.synchronize()
-        rep = {"ran": True, "backend": dist.get_backend(), "world": dist.get_world_size(),
-               "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()),
-               "all_gather_equals_local": bool(torch.equal(sh.gathered[0], sh.local)),
-               "all_gather_ms": round(e0.elapsed_time(e1) / 10.0, 4), "bytes": int(sh.local.numel() * 8),
-               "note": "world-size-1 group on this GPU, outside the timed region: library loading, communicator and the "
-                       "collective on the frame's f64 buffers; says nothing about xGMI"}
-        dist.destroy_process_group()
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        with tempfile.TemporaryDirectory() as tmp:
+            t0 = time.perf_counter()
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_child.py"), tmp, "64", "48", "8", "7"], env=env,
+                               capture_output=True, text=True, timeout=180)
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                return {"ran": False, "error": (p.stderr or p.stdout)[-300:]}
+            with open(os.path.join(tmp, "report.json")) as f:
+                child = json.load(f)
+        rep = {"ran": True, "backend": child["backend"], "world": child["world"], "rccl_version": child["rccl_version"],
+               "all_gather_equals_local": bool(child["sets_gather_equals_local"] and child["rows_gather_equals_local"]),
+               "all_reduce_ok": child["all_reduce_ok"], "one_hip_runtime": len(child["libamdhip64"]) == 1,
+               "librccl": child["librccl"], "child_wall_s": round(dt, 2),
+               "note": "world-size-1 group in a fresh child on this GPU, outside the timed region: library loading beside "
+                       "libflux_hip.so, communicator, and the collectives on the sharders' f64 buffers; says nothing about xGMI"}
     except Exception as ex:  # noqa: BLE001 -- a probe: report, never fail the bench
         rep = {"ran": False, "error": f"{type(ex).__name__}: {ex}"[:300]}
     return rep
@@ -428,7 +429,7 @@ def main():
             "reference_equivalent_s": round(t_create + elapsed_max / a.steps, 4),
         }
         if world == 1:
-            out["rccl_probe"] = rccl_probe(sh, dev)
+            out["rccl_probe"] = rccl_probe(int(sh.local.numel() * 8))
         if world == 1 and not a.no_cpu_baseline:
             if a.scene.startswith("hf:"):
                 # the CPU checker scans every triangle per ray (it DEFINES what the BVH must reproduce): ~5 ms per ray on
