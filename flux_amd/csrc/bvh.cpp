@@ -13,6 +13,9 @@
 #include <cstring>
 #include <limits>
 
+#ifndef FLUX_BVH_BINS
+#define FLUX_BVH_BINS 16
+#endif
 #ifndef FLUX_BVH_COLLAPSE_MODE
 #define FLUX_BVH_COLLAPSE_MODE 0
 #endif
@@ -97,7 +100,7 @@ struct Builder {
         for (uint32_t k = b; k < e; k++) cb.grow(prims[order[k]].c);
         int best_axis = -1, best_bin = -1;
         double best_cost = std::numeric_limits<double>::infinity();
-        constexpr int NB = 16;
+        constexpr int NB = FLUX_BVH_BINS;
         const bool allow_sah = depth < kBvhSahDepth;
         if (allow_sah) {
             for (int a = 0; a < 3; a++) {
