@@ -61,6 +61,9 @@
 #ifndef FLUX_WPE_BVH4
 #define FLUX_WPE_BVH4 4           // waves/SIMD of render_bvh4_kernel: 122 VGPRs, no scratch (at 5: 96 VGPRs, 48 spilled, 180 vs 160 ms)
 #endif
+#ifndef FLUX_BVH4_ENTRY
+#define FLUX_BVH4_ENTRY 1         // render_bvh4_kernel: a pixel's camera rays enter the tree where its ray bundle first reaches two children
+#endif
 #ifndef FLUX_BVH_REFILL_AT
 #define FLUX_BVH_REFILL_AT 40     // lanes that must be waiting for shading before the wave leaves traversal (swept 16..64 with the leaf vote)
 #endif
