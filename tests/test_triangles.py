@@ -211,6 +211,51 @@ def test_wide_and_binary_state_machines_agree(flux, demo2, nx, nz, n):
     assert out["brute"][1]["bvh_nodes"] == 0 and out["brute"][1]["tris_tested"] == out["brute"][1]["segments"] * 2 * nx * nz
 
 
+_ENTRY_CAMERAS = {
+    "pinhole": dict(lens_radius=0.0),
+    "wide_lens": dict(lens_radius=0.8, focal_distance=6.0),
+    "lens_past_focus": dict(lens_radius=0.4, focal_distance=1.5),                 # the whole mesh lies beyond the focal plane
+    "inside_the_box": dict(eye=(0.5, 0.05, -3.0), look_at=(0.0, 0.0, 8.0)),         # eye between the terrain's lowest and highest point
+    "from_below": dict(eye=(2.0, -0.9, 1.0), look_at=(0.0, 0.3, 4.0)),
+    "far_zoomed": dict(eye=(0.0, 5.5e4, -9.0e4), look_at=(0.0, 1.0, 0.0), zoom_factor=1.5e4, focal_distance=1.0e5),
+    "sideways_up": dict(eye=(-20.0, 0.2, 5.0), look_at=(0.0, 0.0, 5.0), up=(0.0, 0.0, 1.0)),
+    "misses_the_mesh": dict(eye=(0.0, 5.0, -9.0), look_at=(0.0, 40.0, -9.5)),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("camera", sorted(_ENTRY_CAMERAS))
+def test_camera_ray_entry_nodes(flux, demo2, camera):
+    """render_bvh4_kernel starts a pixel's camera rays below the part of the tree the pixel's ray bundle (lens x pixel
+    footprint) cannot reach (pixel_entry_node).  The skipped boxes must hold nothing any ray of the bundle can hit: for
+    cameras that stress the bundle's bounds -- no lens, a wide one, a focal plane in front of the mesh, an eye inside the
+    mesh's bounding box, below it, very far away, a rolled view, a view that misses the mesh -- the 4-wide walk, the binary
+    walk (which has no entry nodes) and brute force take identical decisions."""
+    from flux_amd.procedural import heightfield_scene
+    sd = heightfield_scene(60, 40, seed=21, base=small_scene(demo2, 40, 30))
+    kw = _ENTRY_CAMERAS[camera]
+    cs, cd = sd.camera_settings, sd.camera_data
+    cs.eye, cs.look_at, cs.up = kw.get("eye", cs.eye), kw.get("look_at", cs.look_at), kw.get("up", cs.up)
+    cd.lens_radius = kw.get("lens_radius", cd.lens_radius)
+    cd.focal_distance = kw.get("focal_distance", cd.focal_distance)
+    cd.zoom_factor = kw.get("zoom_factor", cd.zoom_factor)
+    with flux.Renderer(sd, flux.JobConfiguration(8, 5, 50), seed=9) as r:
+        assert r.bvh_info()["wide_in_use"] == 1
+        r.enable_stats(True)
+        out = {}
+        for name, trav in (("wide", flux._lib.TRAVERSE_BVH), ("binary", flux._lib.TRAVERSE_BVH_BINARY), ("brute", flux._lib.TRAVERSE_BRUTE)):
+            r.set_traversal(trav)
+            r.stats(reset=True)
+            img = r.render_frame()
+            out[name] = (img, r.stats(reset=True))
+    drop = ("bvh_nodes", "tris_tested")
+    core = {k: {a: b for a, b in v[1].items() if a not in drop} for k, v in out.items()}
+    assert core["wide"] == core["binary"] == core["brute"], camera
+    assert max_abs_diff(out["wide"][0], out["brute"][0]) < 1e-13 and max_abs_diff(out["binary"][0], out["brute"][0]) < 1e-13
+    if camera == "misses_the_mesh":   # every camera ray's walk ends before its first node
+        assert out["wide"][1]["bvh_nodes"] < out["binary"][1]["bvh_nodes"] // 4
+
+
 @pytest.mark.gpu
 def test_bvh_stats_and_degenerate_meshes(flux, oracle_mod, demo2):
     from flux_amd.procedural import heightfield_scene
