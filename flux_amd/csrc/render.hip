@@ -61,6 +61,12 @@
 #ifndef FLUX_WPE_BVH4
 #define FLUX_WPE_BVH4 4           // waves/SIMD of render_bvh4_kernel: 122 VGPRs, no scratch (at 5: 96 VGPRs, 48 spilled, 180 vs 160 ms)
 #endif
+#ifndef FLUX_BVH4_EARLY_REFILL
+#define FLUX_BVH4_EARLY_REFILL 1  // render_bvh4_kernel: the node loop is left for the shading step as soon as FLUX_BVH_REFILL_AT walks have ended
+#endif
+#ifndef FLUX_BVH4_EARLY_AT
+#define FLUX_BVH4_EARLY_AT 48     //   ... that many
+#endif
 #ifndef FLUX_BVH4_ENTRY
 #define FLUX_BVH4_ENTRY 1         // render_bvh4_kernel: a pixel's camera rays enter the tree where its ray bundle first reaches two children
 #endif
