@@ -547,6 +547,21 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.uni_idx[1] = uni_idx[1];
     rp.unit_dirs = rp.glossy_long ? 0 : 1;
     rp.self_skip = (FLUX_SELF_SKIP && !rp.glossy_long) ? 1 : 0;
+    {   // the environment shortcut (flux_device.h env_short): exactly one `invert` sphere, Emissive, of ordinary size
+        int inverted = 0;
+        for (const flux::DevHitRec &hr : frec_s)
+            if (hr.inv_rad < 0.0) inverted++;
+        rp.env_short = 0;
+        rp.pad_env = 0;
+        rp.env_radius = 0.0;
+        if (FLUX_ENV_SHORT && n_uni == 1 && inverted == 1 && frec_s[uni_idx[0]].mat_kind == flux::kMatEmissive) {
+            const double rad = std::sqrt(fsph[uni_idx[0]].rr);
+            if (rad > 1e-3 && rad < 1e6) {
+                rp.env_short = 1;
+                rp.env_radius = rad * (1.0 + 1e-12);  // never below the true radius: it bounds the exit distance from above
+            }
+        }
+    }
     for (const flux::DevScanSphere &sp : fsph)
         if (!(std::fabs(sp.px) < 1e3 && std::fabs(sp.py) < 1e3 && std::fabs(sp.pz) < 1e3 && sp.rr < 1e6)) rp.self_skip = 0;
     rp.n_sph = (int32_t)fsph.size();
@@ -618,6 +633,7 @@ int flux_debug_shade(flux_ctx *ctx, uint64_t n, const double *rays, uint64_t dep
     p.glossy_long = 1;  // caller-supplied directions need not be unit vectors
     p.unit_dirs = 0;
     p.self_skip = 0;
+    p.env_short = 0;
     if (int rc = check_lds_budget_rays(ctx, p)) {
         (void)hipFree(d_rays);
         (void)hipFree(d_rgb);

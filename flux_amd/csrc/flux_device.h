@@ -28,6 +28,10 @@
 #ifndef FLUX_UNIT_DIRS
 #define FLUX_UNIT_DIRS 1
 #endif
+// FAST split kernel, phase B: 1 = an Emissive environment sphere is decided without its square root (RenderParams::env_short)
+#ifndef FLUX_ENV_SHORT
+#define FLUX_ENV_SHORT 1
+#endif
 // FAST mesh scenes: 1 = render_bvh4_kernel over the 4-wide tree (flux_bvh.h), 0 = render_bvh_kernel over the binary one
 #ifndef FLUX_BVH_WIDE
 #define FLUX_BVH_WIDE 1
@@ -225,6 +229,11 @@ struct RenderParams {
     // FAST: 1 = no plane is stored with a non-unit normal (= !glossy_long) and the rays are the render loop's own: every
     // ray direction is then a unit vector to rounding and scan_shapes_fast skips its normalisation
     int32_t unit_dirs;
+    // FAST: 1 = the scene's ONE `invert` sphere is Emissive (an environment): a secondary ray that starts well inside it
+    // always reaches it, what it emits does not depend on where, so the split kernel decides "nearer than the best hit so
+    // far?" on squared quantities and takes no square root (render_body.inc scan_shapes_fast<true>); env_radius = its radius
+    int32_t env_short, pad_env;
+    double env_radius;
 };
 
 }  // namespace flux

@@ -404,13 +404,32 @@ def _env_cases(flux, demo2):
     sd = copy.deepcopy(base)
     sd.shapes = copy.deepcopy(base.shapes) + [flux.SphereData((0.0, 1504.0, 0.0), 1500.0, mats["matte"], False)]
     cases["beyond_the_magnitude_guard"] = sd
+    # the split kernel's square-root-free decision for an Emissive environment (RenderParams::env_short): surfaces that
+    # meet the environment sphere, so that "nearer than the best hit so far" is decided at and around equality, and
+    # bounce origins closer to it than its margin -- the cases its fallback to the exact code exists for
+    R, c = float(env.radius), tuple(float(x) for x in env.center)
+    sd = copy.deepcopy(base)
+    sd.shapes = [s for s in copy.deepcopy(base.shapes) if not isinstance(s, flux.PlaneData)] + [
+        flux.PlaneData((c[0], c[1] - R + 0.02, c[2]), (0.0, 1.0, 0.0), mats["matte"])]   # cuts a cap of radius 2 off its lowest point
+    sd.camera_settings.eye, sd.camera_settings.look_at = (c[0], c[1] - R + 3.0, c[2] - 6.0), (c[0], c[1] - R, c[2])
+    cases["plane_tangent_to_the_environment"] = sd
+    sd = copy.deepcopy(base)
+    sd.shapes = copy.deepcopy(base.shapes) + [flux.SphereData((c[0], c[1] + 6.0, c[2] + R - 4.0), 9.0, mats["matte"], False)]  # crosses it
+    sd.camera_settings.eye, sd.camera_settings.look_at = (c[0], c[1] + 6.0, c[2] + R - 30.0), (c[0], c[1] + 6.0, c[2] + R)
+    cases["sphere_across_the_environment"] = sd
+    sd = copy.deepcopy(base)
+    sd.shapes = copy.deepcopy(base.shapes) + [flux.SphereData((c[0], c[1] + 2.0, c[2] + R - 1.0001), 1.0, mats["matte"], False),   # 1e-4 short of touching
+                                             flux.SphereData((c[0] + 3.0, c[1] + 2.0, c[2] + R - 1.0), 1.0, mats["glossy"], False)]  # touching
+    sd.camera_settings.eye, sd.camera_settings.look_at = (c[0] + 1.5, c[1] + 2.0, c[2] + R - 9.0), (c[0] + 1.5, c[1] + 2.0, c[2] + R)
+    cases["spheres_touching_the_environment"] = sd
     return cases
 
 
 @pytest.mark.parametrize("variant", [2, 3])
 @pytest.mark.parametrize("case", ["convex_first", "inverted_first", "nested_environments", "camera_outside_environment",
                                   "inside_convex_matte", "inside_convex_glossy", "inside_convex_reflective",
-                                  "beyond_the_magnitude_guard"])
+                                  "beyond_the_magnitude_guard", "plane_tangent_to_the_environment",
+                                  "sphere_across_the_environment", "spheres_touching_the_environment"])
 def test_environment_and_self_leaving_shortcuts(flux, oracle_mod, demo2, case, variant):
     sd = _env_cases(flux, demo2)[case]
     cfg = flux.JobConfiguration(16, 5, 50)   # 256 spp: refill and split kernels
