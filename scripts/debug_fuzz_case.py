@@ -29,4 +29,7 @@ for case in range(40):
                 got = r.render_frame(); st = r.stats()
                 d = {k: st[k] - ost[k] for k in ost if st[k] != ost[k]}
                 fin = np.isfinite(want) & np.isfinite(got)
-                print("math", math, "variant", variant, "diff", d, "max|d|", float(np.abs(got[fin] - want[fin]).max(initial=0.0)))
+                nan_diff = np.argwhere(np.isfinite(want) != np.isfinite(got))
+                print("math", math, "variant", variant, "diff", d, "max|d|", float(np.abs(got[fin] - want[fin]).max(initial=0.0)),
+                      "non-finite: oracle", int((~np.isfinite(want)).sum()), "gpu", int((~np.isfinite(got)).sum()),
+                      "where they differ", [(tuple(int(x) for x in ix), float(want[tuple(ix)]), float(got[tuple(ix)])) for ix in nan_diff[:6]])
