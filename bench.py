@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--shard", default="auto", choices=["auto", "rows", "sets"],
                     help="how the frame is split over GPUs: interleaved rows, or sample sets (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rccl-probe", action="store_true",
+                    help="skip the world-size-1 RCCL child after the timed region (profiling passes: a second GPU process under "
+                         "the rocprofv3 preload would put its kernels into the counter files)")
     ap.add_argument("--cpu-root", type=int, default=None, help="sample_root of the bounded CPU-baseline sample")
     a = ap.parse_args()
     scene, root = CONFIGS[a.config if a.config is not None else 4]
@@ -96,6 +99,25 @@ def cpu_baseline(sd, depth, seed, cpu_root):
             "sample": f"{sd.scene_name}.yml full {W}x{H} frame at {cpu_root * cpu_root} spp (sample_root {cpu_root}), "
                       f"depth {depth}, seed {seed}: {samples / 1e6:.1f} Msamples in {dt:.2f} s on {cores} threads "
                       f"(row-parallel); table build {t_tables:.2f} s excluded, as for the GPU value"}
+
+
+def cpu_single_thread(depth, seed):
+    """BASELINE.json configs[0] / BASELINE.md section 3: scenes/demo1.yml at 16 spp (sample_root 4), 800x600, ONE host thread --
+    Camera::render (trace.rs:53-97) on one core, as restated by the oracle (kind 'port'): 7.68 M samples, about 2 s."""
+    import flux_amd
+    from oracle import oracle
+    sd = flux_amd.load_scene(os.path.join(ROOT, "scenes", "demo1.yml"))
+    cfg = flux_amd.JobConfiguration(4, depth, 50)
+    o = oracle.Oracle(sd, cfg, seed=seed)
+    t0 = time.perf_counter()
+    o.render_frame(threads=1)
+    dt = time.perf_counter() - t0
+    o.close()
+    W, H = sd.output_settings.image_width, sd.output_settings.image_height
+    samples = W * H * 16
+    return {"value": round(samples / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"demo1.yml full {W}x{H} frame at 16 spp (sample_root 4), depth {depth}, seed {seed}: "
+                      f"{samples / 1e6:.2f} Msamples in {dt:.2f} s on 1 thread (BASELINE.json configs[0])"}
 
 
 def load_profile(scene_label, kernel_name):
@@ -295,6 +317,11 @@ def main():
         dist.all_reduce(stt, op=dist.ReduceOp.SUM)
     tot_samples, tot_matte, tot_segments, tot_glossy, tot_nodes, tot_tris, tot_miss = [float(x) for x in stt]
     bvh = r.bvh_info()
+    # the kernel the timed call launched: asked of the library's launch planner for exactly that call (never re-derived here)
+    plan = r.launch_plan(num_sets=sh.count) if use_sets else r.launch_plan(num_rows=sh.count)
+    kernel_name = {flux_amd._lib.PLAN_STATIC: "render_static_kernel", flux_amd._lib.PLAN_REFILL: "render_refill_kernel",
+                   flux_amd._lib.PLAN_SPLIT: "render_split_kernel", flux_amd._lib.PLAN_BVH_BINARY: "render_bvh_kernel",
+                   flux_amd._lib.PLAN_BVH4: "render_bvh4_kernel"}.get(plan["kernel"], "none")
 
     if rank == 0:
         samples = W * H * n * n
@@ -309,8 +336,7 @@ def main():
         # as laid out for the kernel that ran: 64-B 4-wide nodes and 128-B leaf records holding one or two triangles (counted
         # per triangle test at 64 B when the record is a quad's) for render_bvh4_kernel; 32-B nodes (two 16-B gathers of a
         # DevNodeQ) + 80 B of a DevTri for the binary-tree kernel; the inline walk of the other kernels reads DevNode / DevTri
-        wide = bool(bvh.get("wide_in_use")) and a.math == "fast" and n * n >= 64 and a.kernel != 1
-        if wide:
+        if plan["kernel"] == flux_amd._lib.PLAN_BVH4:
             tri_b = bvh["leaf_record_bytes"] * bvh["leaf_records"] / max(bvh["triangles"], 1)
             bvh_bytes = (tot_nodes * bvh["wide_node_bytes"] + tot_tris * tri_b) / tot_samples
         else:
@@ -321,13 +347,6 @@ def main():
         alg_bytes_launch = samples_launch * bytes_per_sample + (H * W / world) * 24.0
         alg_gbs = alg_bytes_launch / (kernel_ms_max * 1e-3) / 1e9
         workload = f"{scene_label} {W}x{H} at {n * n} spp (sample_root {n}), depth {a.depth}, seed {a.seed}"
-        dyn = n * n >= 64 and a.kernel != 1
-        if dyn and a.math == "fast" and bvh["triangles"] > 0:
-            kernel_name = "render_bvh4_kernel" if bvh.get("wide_in_use") else "render_bvh_kernel"
-        elif dyn and a.math == "fast" and a.kernel in (0, 3) and n * n >= (256 if a.kernel == 0 else 64) and bvh["triangles"] == 0:
-            kernel_name = "render_split_kernel"
-        else:
-            kernel_name = "render_refill_kernel" if dyn else "render_static_kernel"
         prof = load_profile(scene_label, kernel_name)
         # counters of the committed rocprofv3 PMC passes of this scene + kernel, carried per sample (NOT measured in this
         # run: `from_committed_profile`)
@@ -374,7 +393,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": workload, "scene": scene_label, "kernel": kernel_name.replace("render_", "").replace("_kernel", ""),
-                       "math": a.math,
+                       "math": a.math, "waves_per_pixel": plan["waves_per_pixel"], "threads_per_block": plan["block"],
+                       "blocks_per_launch": plan["blocks"],
                        "parallelism": (f"pixel-set tiles (one pixel per row per owned sample set; each rank holds only its "
                                        f"sets' tables) over {world} GPU(s), 1 all_gather" if use_sets else
                                        f"row-interleaved image tiles over {world} GPU(s), 1 all_gather"),
@@ -428,7 +448,7 @@ def main():
             "ctx_create_ms": round(t_create * 1e3, 1),
             "reference_equivalent_s": round(t_create + elapsed_max / a.steps, 4),
         }
-        if world == 1:
+        if world == 1 and not a.no_rccl_probe:
             out["rccl_probe"] = rccl_probe(int(sh.local.numel() * 8))
         if world == 1 and not a.no_cpu_baseline:
             if a.scene.startswith("hf:"):
@@ -437,6 +457,7 @@ def main():
                 out["cpu_baseline"] = None
             else:
                 out["cpu_baseline"] = cpu_baseline(sd, a.depth, a.seed, a.cpu_root)
+                out["cpu_baseline"]["single_thread"] = cpu_single_thread(a.depth, a.seed)
         print(json.dumps(out), flush=True)
     r.close()
     if world > 1:

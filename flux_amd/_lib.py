@@ -21,6 +21,10 @@ SAMPLER_REGULAR, SAMPLER_JITTERED, SAMPLER_MULTI_JITTERED, SAMPLER_CORRELATED_MU
 TABLE_PIXEL, TABLE_DISC, TABLE_HEMI = 0, 1, 2
 TRAVERSE_BVH, TRAVERSE_BRUTE, TRAVERSE_BVH_BINARY = 0, 1, 2
 NUM_STATS = 16
+BVH_INFO_WORDS = 16
+PLAN_WORDS = 8
+PLAN_NONE, PLAN_STATIC, PLAN_REFILL, PLAN_SPLIT, PLAN_BVH_BINARY, PLAN_BVH4 = -1, 0, 1, 2, 3, 4
+ABI_VERSION = 2
 
 
 class FluxMaterial(C.Structure):
@@ -85,7 +89,8 @@ SYMBOLS = {
                                     C.POINTER(C.c_double)]),
     "flux_debug_fastmath": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.c_uint64]),
-    "flux_ctx_bvh_info": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "flux_ctx_bvh_info": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_uint64]),
+    "flux_ctx_launch_plan": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_int64)]),
     "flux_ctx_last_kernel_ms": (C.c_double, [_P]),
     "flux_ctx_enable_stats": (C.c_int, [_P, C.c_int]),
     "flux_ctx_stats": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
@@ -128,6 +133,9 @@ def _load():
 
 
 lib = _load()
+if lib.flux_abi_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH} speaks ABI version {lib.flux_abi_version()}, this binding {ABI_VERSION}: rebuild it "
+                      "(python -m flux_amd.build --force)")
 
 
 def last_error():

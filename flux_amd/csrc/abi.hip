@@ -577,7 +577,7 @@ static bool holds_all_sets(const flux_ctx *c) { return c->sets.stride == 1 && c-
 // level per lane -- 64 lanes in the FAST state-machine kernel, the block's in the others --; the split kernel its path
 // queues), plus the few static words of the refill / split kernels.  64 KiB per block is the launch limit.
 static int check_lds_budget(const flux_ctx *ctx, const flux::RenderParams &p, const char *what) {
-    const size_t dyn = flux::render_lds_bytes(p, ctx->variant, ctx->math);
+    const size_t dyn = flux::plan_render(p, ctx->variant, ctx->math).lds;
     const size_t fixed = 512;
     if (dyn + fixed > 64 * 1024)
         return fail(FLUX_E_INVALID, "%s: %zu B of LDS per block (max_trace_depth %u%s, BVH depth %llu) exceed the 64 KiB limit; "
@@ -701,6 +701,58 @@ int flux_debug_fastmath(int device, int fn, const double *a, const double *b, do
     return FLUX_OK;
 }
 
+// The work fields of a launch: ONE place per entry point, shared by the render call and flux_ctx_launch_plan.
+static flux::RenderParams apply_traversal(const flux_ctx *ctx, flux::RenderParams p) {
+    p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
+    if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
+    if (ctx->traversal == FLUX_TRAVERSE_BVH_BINARY) p.nodes4 = nullptr;
+    return p;
+}
+static flux::RenderParams rows_params(const flux_ctx *ctx, uint64_t first_row, uint64_t row_stride, uint64_t num_rows, double *out) {
+    flux::RenderParams p = ctx->rp;
+    p.out = out;
+    p.first_row = (int32_t)first_row;
+    p.row_stride = (int32_t)row_stride;
+    p.num_rows = (int32_t)num_rows;
+    return apply_traversal(ctx, p);
+}
+static flux::RenderParams sets_params(const flux_ctx *ctx, uint64_t first_set, uint64_t set_stride, uint64_t num_sets, double *out) {
+    flux::RenderParams p = ctx->rp;
+    p.out = out;
+    p.first_row = 0;
+    p.row_stride = 1;
+    p.num_rows = (int32_t)ctx->H;
+    p.set_first = (int32_t)first_set;
+    p.set_stride = (int32_t)set_stride;
+    p.set_count = (int32_t)num_sets;
+    p.out_by_set = 1;
+    p.slot_first = (int32_t)((first_set - ctx->sets.first) / ctx->sets.stride);
+    p.slot_stride = (int32_t)(set_stride / ctx->sets.stride);
+    return apply_traversal(ctx, p);
+}
+
+int flux_ctx_launch_plan(flux_ctx *ctx, uint64_t num_rows, uint64_t num_sets, int64_t out[FLUX_PLAN_WORDS]) {
+    if (!ctx || !out) return fail(FLUX_E_INVALID, "null argument");
+    if (num_rows > ctx->H) return fail(FLUX_E_INVALID, "%llu rows exceed image height %u", (unsigned long long)num_rows, ctx->H);
+    flux::RenderParams p;
+    if (num_sets == 0) {
+        p = rows_params(ctx, 0, 1, num_rows, nullptr);
+    } else {
+        const uint64_t held = ctx->sets.count;
+        if (num_sets > held) return fail(FLUX_E_INVALID, "%llu sets exceed the %llu this context holds", (unsigned long long)num_sets,
+                                         (unsigned long long)held);
+        p = sets_params(ctx, ctx->sets.first, ctx->sets.stride, num_sets, nullptr);
+    }
+    const flux::LaunchPlan L = flux::plan_render(p, ctx->variant, ctx->math);
+    out[0] = L.kernel;
+    out[1] = L.block;
+    out[2] = (int64_t)L.blocks;
+    out[3] = (int64_t)L.lds;
+    out[4] = L.waves_per_pixel;
+    out[5] = out[6] = out[7] = 0;
+    return FLUX_OK;
+}
+
 int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stride, uint64_t num_rows,
                             void *d_out_rgb, void *hip_stream) {
     if (!ctx) return fail(FLUX_E_INVALID, "null context");
@@ -717,14 +769,7 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(FLUX_E_DEVICE, "hipSetDevice(%d) failed", ctx->device);
     hipStream_t stream = (hipStream_t)hip_stream;
-    flux::RenderParams p = ctx->rp;
-    p.out = (double *)d_out_rgb;
-    p.first_row = (int32_t)first_row;
-    p.row_stride = (int32_t)row_stride;
-    p.num_rows = (int32_t)num_rows;
-    p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
-    if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
-    if (ctx->traversal == FLUX_TRAVERSE_BVH_BINARY) p.nodes4 = nullptr;
+    const flux::RenderParams p = rows_params(ctx, first_row, row_stride, num_rows, (double *)d_out_rgb);
     if (int rc = check_lds_budget(ctx, p, "flux_render_rows")) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
@@ -752,20 +797,7 @@ int flux_render_sets_device(flux_ctx *ctx, uint64_t first_set, uint64_t set_stri
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return fail(FLUX_E_DEVICE, "hipSetDevice(%d) failed", ctx->device);
     hipStream_t stream = (hipStream_t)hip_stream;
-    flux::RenderParams p = ctx->rp;
-    p.out = (double *)d_out_rgb;
-    p.first_row = 0;
-    p.row_stride = 1;
-    p.num_rows = (int32_t)ctx->H;
-    p.set_first = (int32_t)first_set;
-    p.set_stride = (int32_t)set_stride;
-    p.set_count = (int32_t)num_sets;
-    p.out_by_set = 1;
-    p.slot_first = (int32_t)((first_set - ctx->sets.first) / ctx->sets.stride);
-    p.slot_stride = (int32_t)(set_stride / ctx->sets.stride);
-    p.stats = ctx->stats_on ? ctx->d_stats : nullptr;
-    if (ctx->traversal == FLUX_TRAVERSE_BRUTE) p.bvh_stack = 0;
-    if (ctx->traversal == FLUX_TRAVERSE_BVH_BINARY) p.nodes4 = nullptr;
+    const flux::RenderParams p = sets_params(ctx, first_set, set_stride, num_sets, (double *)d_out_rgb);
     if (int rc = check_lds_budget(ctx, p, "flux_render_sets_device")) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
@@ -820,25 +852,25 @@ int flux_ctx_set_traversal(flux_ctx *ctx, int mode) {
     return FLUX_OK;
 }
 
-int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t out[FLUX_BVH_INFO_WORDS]) {
+int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t *out, uint64_t out_words) {
     if (!ctx || !out) return fail(FLUX_E_INVALID, "null argument");
-    out[0] = ctx->bvh.nodes;
-    out[1] = ctx->bvh.tris;
-    out[2] = ctx->bvh.max_depth;
-    out[3] = ctx->bvh.max_leaf;
-    out[4] = sizeof(flux::DevNode);
-    out[5] = sizeof(flux::DevTri);
-    out[6] = ctx->bvh.build_us;
-    out[7] = ctx->bvh.wide_nodes;
-    out[8] = ctx->bvh.leaf_records;
-    out[9] = ctx->bvh.fused_leaves;
-    out[10] = ctx->bvh.wide_stack;
-    out[11] = sizeof(flux::DevNode4Q);
-    out[12] = sizeof(flux::DevLeafRec);
-    // [13]: 1 = FAST mesh renders of >= 64 spp walk the 4-wide tree (render_bvh4_kernel), 0 = the binary one (render_bvh_kernel)
-    out[13] = (FLUX_BVH_WIDE && ctx->d_nodes4 != nullptr && ctx->bvh.wide_stack <= FLUX_BVH_WIDE_MAX_STACK &&
-               ctx->traversal == FLUX_TRAVERSE_BVH) ? 1 : 0;
-    out[14] = out[15] = 0;
+    uint64_t w[FLUX_BVH_INFO_WORDS] = {};
+    w[0] = ctx->bvh.nodes;
+    w[1] = ctx->bvh.tris;
+    w[2] = ctx->bvh.max_depth;
+    w[3] = ctx->bvh.max_leaf;
+    w[4] = sizeof(flux::DevNode);
+    w[5] = sizeof(flux::DevTri);
+    w[6] = ctx->bvh.build_us;
+    w[7] = ctx->bvh.wide_nodes;
+    w[8] = ctx->bvh.leaf_records;
+    w[9] = ctx->bvh.fused_leaves;
+    w[10] = ctx->bvh.wide_stack;
+    w[11] = sizeof(flux::DevNode4Q);
+    w[12] = sizeof(flux::DevLeafRec);
+    // [13]: asked of the launch planner (a full-frame render with the current variant, arithmetic and traversal)
+    w[13] = flux::plan_render(rows_params(ctx, 0, 1, ctx->H, nullptr), ctx->variant, ctx->math).kernel == FLUX_PLAN_BVH4 ? 1 : 0;
+    for (uint64_t k = 0; k < out_words && k < FLUX_BVH_INFO_WORDS; k++) out[k] = w[k];
     return FLUX_OK;
 }
 

@@ -24,8 +24,18 @@ hipError_t hemi_to_aos(size_t SD, size_t N, const double *in, double *out, hipSt
 // Camera::render (trace.rs:53-97).  variant: FLUX_KERNEL_STATIC / FLUX_KERNEL_REFILL;
 // math: FLUX_MATH_FAST / FLUX_MATH_STRICT (render_body.inc).
 hipError_t launch_render(const RenderParams &p, int variant, int math, hipStream_t stream);
-// dynamic LDS per block of the kernel launch_render picks for these parameters (render.hip)
-size_t render_lds_bytes(const RenderParams &p, int variant, int math);
+// Which kernel launch_render runs for these parameters, with what block size, grid and dynamic LDS: decided in ONE place
+// (render_body.inc plan_render_impl) and asked from there by the host's LDS budget check, by flux_ctx_launch_plan /
+// flux_ctx_bvh_info and by the launch itself, so that they cannot drift apart.
+struct LaunchPlan {
+    int kernel;  // FLUX_PLAN_* (include/flux_abi.h): 0 static, 1 refill, 2 split, 3 BVH state machine over the binary tree,
+                 // 4 the same over the 4-wide tree; -1 nothing to do
+    unsigned block;
+    uint64_t blocks;
+    size_t lds;  // dynamic LDS per block (the refill / split kernels add 96 B of static LDS)
+    unsigned waves_per_pixel;  // K: waves that share one pixel's samples (1 in the static and BVH kernels)
+};
+LaunchPlan plan_render(const RenderParams &p, int variant, int math);
 
 // Scene::shade for caller-supplied rays (device pointers; rays = n x (origin, direction)).
 hipError_t launch_shade_rays(const RenderParams &p, int math, const double *d_rays, int n, int depth, uint32_t set,

@@ -73,6 +73,10 @@
 #ifndef FLUX_BVH_REFILL_AT
 #define FLUX_BVH_REFILL_AT 40     // lanes that must be waiting for shading before the wave leaves traversal (swept 16..64 with the leaf vote)
 #endif
+// the early exit leaves the node loop when EARLY_AT walks have ended and expects the shading step to follow: with
+// EARLY_AT < REFILL_AT the wave would re-enter the loop on the same counts and never advance
+static_assert(!FLUX_BVH4_EARLY_REFILL || FLUX_BVH4_EARLY_AT >= FLUX_BVH_REFILL_AT,
+              "FLUX_BVH4_EARLY_AT must not be below FLUX_BVH_REFILL_AT (render_bvh4_kernel would livelock)");
 #ifndef FLUX_WPE_SPLIT
 #define FLUX_WPE_SPLIT 4          // waves/SIMD of the split kernel (two path states live in phase A)
 #endif
@@ -141,9 +145,9 @@ hipError_t launch_render(const RenderParams &p, int variant, int math, hipStream
     return fast::launch_render_impl(p, variant, stream);
 }
 
-// dynamic LDS per block of the kernel launch_render would pick (host-side budget check)
-size_t render_lds_bytes(const RenderParams &p, int variant, int math) {
-    return math == FLUX_MATH_STRICT ? strict::plan_render_impl(p, variant).lds : fast::plan_render_impl(p, variant).lds;
+// the kernel, grid and LDS launch_render would pick (host-side budget check, flux_ctx_launch_plan)
+LaunchPlan plan_render(const RenderParams &p, int variant, int math) {
+    return math == FLUX_MATH_STRICT ? strict::plan_render_impl(p, variant) : fast::plan_render_impl(p, variant);
 }
 
 hipError_t launch_shade_rays(const RenderParams &p, int math, const double *d_rays, int n, int depth, uint32_t set,

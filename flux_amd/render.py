@@ -139,10 +139,19 @@ class Renderer:
         _lib.check(_lib.lib.flux_ctx_set_traversal(self._handle(), mode))
 
     def bvh_info(self) -> dict:
-        buf = (C.c_uint64 * 16)()
-        _lib.check(_lib.lib.flux_ctx_bvh_info(self._handle(), buf))
+        buf = (C.c_uint64 * _lib.BVH_INFO_WORDS)()
+        _lib.check(_lib.lib.flux_ctx_bvh_info(self._handle(), buf, _lib.BVH_INFO_WORDS))
         names = ("nodes", "triangles", "max_depth", "max_leaf", "node_bytes", "tri_bytes", "build_us", "wide_nodes",
                  "leaf_records", "fused_leaves", "wide_stack", "wide_node_bytes", "leaf_record_bytes", "wide_in_use")
+        return dict(zip(names, [int(x) for x in buf]))
+
+    def launch_plan(self, num_rows=None, num_sets: int = 0) -> dict:
+        """What a render call would launch with the current settings (flux_ctx_launch_plan: the library's own launch
+        planner): `num_rows` rows of all sets (flux_render_rows*), or `num_sets` of this context's sets over all rows
+        (flux_render_sets_device) when num_sets > 0."""
+        buf = (C.c_int64 * _lib.PLAN_WORDS)()
+        _lib.check(_lib.lib.flux_ctx_launch_plan(self._handle(), self.height if num_rows is None else num_rows, num_sets, buf))
+        names = ("kernel", "block", "blocks", "lds", "waves_per_pixel")
         return dict(zip(names, [int(x) for x in buf]))
 
     def table(self, which: int) -> np.ndarray:

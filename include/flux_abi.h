@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define FLUX_ABI_VERSION 1
+/* 2: flux_ctx_bvh_info writes FLUX_BVH_INFO_WORDS = 16 words (version 1 documented 8) and takes the caller's capacity;
+ *    flux_ctx_launch_plan added. */
+#define FLUX_ABI_VERSION 2
 
 /* error codes */
 #define FLUX_OK 0
@@ -236,9 +238,25 @@ int flux_ctx_stats(flux_ctx *ctx, uint64_t out[FLUX_NUM_STATS], int reset);
 /* BVH introspection (extension): out[0] nodes of the binary tree, [1] triangles, [2] its max depth, [3] max leaf size,
  * [4] its node bytes, [5] triangle-record bytes, [6] build microseconds; the 4-wide tree the FAST traversal kernel walks:
  * [7] nodes, [8] leaf records, [9] of them holding two triangles (the halves of a quad), [10] most stack entries at once,
- * [11] node bytes, [12] leaf-record bytes, [13] 1 if FAST renders walk the 4-wide tree (0: the binary one); [14..15] reserved (0). */
+ * [11] node bytes, [12] leaf-record bytes, [13] 1 if a full-frame render with the context's current settings walks the
+ * 4-wide tree (flux_ctx_launch_plan's kernel == FLUX_PLAN_BVH4); [14..15] reserved (0).
+ * Writes min(out_words, FLUX_BVH_INFO_WORDS) words: a caller states the capacity of its buffer. */
 #define FLUX_BVH_INFO_WORDS 16
-int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t out[FLUX_BVH_INFO_WORDS]);
+int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t *out, uint64_t out_words);
+
+/* What a render call WOULD launch with the context's current kernel variant, arithmetic and traversal -- the decision
+ * itself (the library's one launch planner), not a restatement of it: for flux_render_rows* of `num_rows` rows when
+ * num_sets == 0, for flux_render_sets_device of `num_sets` sets (all rows) otherwise.
+ * out[0] kernel (FLUX_PLAN_*), [1] threads per block, [2] blocks, [3] dynamic LDS bytes per block,
+ * [4] waves that share one pixel's samples (K: 1, 2 or 4 -- from the sample count only), [5..7] reserved (0). */
+#define FLUX_PLAN_NONE (-1)    /* nothing to launch */
+#define FLUX_PLAN_STATIC 0     /* render_static_kernel */
+#define FLUX_PLAN_REFILL 1     /* render_refill_kernel */
+#define FLUX_PLAN_SPLIT 2      /* render_split_kernel */
+#define FLUX_PLAN_BVH_BINARY 3 /* render_bvh_kernel */
+#define FLUX_PLAN_BVH4 4       /* render_bvh4_kernel */
+#define FLUX_PLAN_WORDS 8
+int flux_ctx_launch_plan(flux_ctx *ctx, uint64_t num_rows, uint64_t num_sets, int64_t out[FLUX_PLAN_WORDS]);
 
 /* Introspection used by the parity tests (device -> host copies).
  * which: 0 = pixel_sets [S][N][2], 1 = disc_sets [S][N][2],

@@ -14,7 +14,11 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) < 2 or sys.argv[1].startswith("-"):
+    sys.exit(__doc__)   # (`--help` used to be taken for a tag and wrote profiles/--help_pmc.json)
 tag = sys.argv[1]
+if not os.path.isdir(os.path.join(ROOT, "gpurun_out", f"prof_{tag}")):
+    sys.exit(f"gpurun_out/prof_{tag}/ not found (scripts/profile_gpu.sh {tag} writes it on the GPU box)")
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -35,8 +39,17 @@ if stats_files:
 
 counters = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = collections.defaultdict(dict)
+def _render_rows(path):
+    try:
+        return sum(1 for r in csv.DictReader(open(path)) if "render_" in r["Kernel_Name"])
+    except Exception:
+        return -1
+
+
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-    for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+    # one file per profiled process: keep the bench's own (the one with the most render-kernel rows), never a child's
+    files = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=_render_rows)
+    for f in files[-1:]:
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"]
             if "render_" not in name:

@@ -27,7 +27,12 @@ def test_header_functions_are_exported(flux):
 
 def test_version_and_error_surface(flux):
     lib = flux._lib.lib
-    assert lib.flux_abi_version() == 1
+    assert lib.flux_abi_version() == 2 == flux._lib.ABI_VERSION
+    header = open(os.path.join(ROOT, "include", "flux_abi.h")).read()
+    assert re.search(r"#define\s+FLUX_ABI_VERSION\s+2\b", header)
+    # introspection calls check their arguments without a device
+    assert lib.flux_ctx_bvh_info(None, None, 16) == flux._lib.E_INVALID
+    assert lib.flux_ctx_launch_plan(None, 0, 0, None) == flux._lib.E_INVALID
     assert lib.flux_device_count() >= 0
     assert lib.flux_ctx_create(None, None, 0, 0, None) == flux._lib.E_INVALID
     assert b"null" in lib.flux_last_error()

@@ -32,4 +32,34 @@ def test_bench_line_contract():
     assert r["achieved"] is not None and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 and 0.0 < r["frac"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "demo1" in c["sample"]
+    one = c["single_thread"]                            # BASELINE.json configs[0]: demo1 @16 spp, one host thread
+    assert one["cores"] == 1 and one["kind"] == "port" and one["value"] > 0 and "16 spp" in one["sample"]
+    assert d["roofline"]["kernel"] == "render_split_kernel" and d["config"]["waves_per_pixel"] == 1
     assert d["rccl_probe"]["ran"] is True and d["rccl_probe"]["backend"] == "nccl" and d["rccl_probe"]["all_gather_equals_local"] is True
+
+
+@pytest.mark.parametrize("shard", ["sets", "rows"])
+def test_bench_multi_rank_branch_rehearsal(shard):
+    """bench.py's N > 1 branch (the reference's fan-out and gather: fluxcore/src/manager.rs:156-162, 316-324), kept alive in
+    the driver's test run although a test box has ONE GPU: FLUX_BENCH_REHEARSE=1 puts both ranks on device 0 and runs the
+    gather over gloo through the host -- everything but RCCL itself (tests/test_gpu_rccl.py covers that at world size 1).
+    The child is a FRESH interpreter: bench.py starts its ranks (torch.distributed.run) before anything touches the GPU.
+    Inside, rank 0 asserts that the path statistics summed over the ranks count exactly W x H x n^2 samples."""
+    env = dict(os.environ, FLUX_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "3", "--steps", "2", "--warmup", "1",
+                        "--shard", shard], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]            # rank 0 prints, once
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and "demo2" in d["metric"]
+    c = d["config"]
+    assert "rehearsal" in c and c["backend"] == "gloo" and c["rccl_ranks"] == 0   # marked: never a measurement
+    assert c["finite"] is True
+    assert ("pixel-set tiles" if shard == "sets" else "row-interleaved") in c["parallelism"]
+    assert d["roofline"]["samples_per_launch"] == 800 * 600 * 1024 / 2            # each rank's launch covers half the frame
+    assert d["roofline"]["kernel"] == "render_split_kernel" and c["waves_per_pixel"] == 1
+    assert "rccl_probe" not in d and "cpu_baseline" not in d                      # N = 1 extras only
+    assert d["step_breakdown_ms"]["render"] > 0 and d["step_breakdown_ms"]["all_gather"] > 0

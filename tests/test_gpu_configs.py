@@ -10,7 +10,7 @@ them in seconds), plus the pieces that only exist for them:
              sphere (scene.rs:156-160 + constants.rs:4: the hit is rejected) -- agree with the oracle ray by ray;
  * config 5  the procedural 1M-triangle height field (extension; flux_amd/procedural.py): BVH traversal == brute force
              over all 1,000,000 triangles on thousands of rays in both arithmetics, identical path statistics on a
-             pixel window, the same horizon-miss behaviour, and ONE FULL 4096-spp FRAME through render_bvh_kernel
+             pixel window, the same horizon-miss behaviour, and ONE FULL 4096-spp FRAME through render_bvh4_kernel
              (determinism, statistics identities, finite / [0,1], rows 330-331 against the static kernel).
 """
 import numpy as np
@@ -294,7 +294,7 @@ def test_config5_state_machine_kernel_and_misses(flux, oracle_mod, hf_scene):
 
 def test_config5_full_frame_at_4096_spp(flux, hf_scene):
     """BASELINE config 5 as stated, on the one GPU a test box has: the whole 800x600 frame of the 1,000,000-triangle scene at
-    4096 spp through render_bvh_kernel (1.97 G camera paths).  No CPU comparison is possible at this size (the oracle scans
+    4096 spp through render_bvh4_kernel, the 4-wide-tree state machine (1.97 G camera paths).  No CPU comparison is possible at this size (the oracle scans
     every triangle per ray), so: bitwise determinism, the statistics identities, finite / [0,1]; and rows 330-331 (the field's
     far edge and the spheres) at the same 4096 spp against the STATIC kernel, whose inline BVH walk shares nothing with the
     state machine but the hit rule -- equal statistics, images to summation order (the static kernel itself equals brute

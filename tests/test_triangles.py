@@ -183,6 +183,64 @@ def test_bvh_of_a_mesh_far_from_the_origin(flux, demo2, offset):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nx,nz", [(0, 0), (3, 2), (24, 16)])
+@pytest.mark.parametrize("where", ["tiny_seen_from_afar", "tiny_at_large_coordinates"])
+def test_rays_whose_padding_exceeds_the_grid(flux, oracle_mod, demo2, nx, nz, where):
+    """the conservative slab padding of a ray, 2^-20 (bvh_mag + |o|), can exceed the WHOLE 16-bit
+    grid of a mesh -- a mesh of 1e-4 seen from 300 units away, or the same mesh at coordinates 1e3 (1e7 times its size) --
+    and then every box passes the f32 test, the inverted boxes of a node's EMPTY slots included; their links used to be
+    stacked like any other, beyond the per-lane stack (sized for the occupied slots: ONE entry for a one-triangle mesh).
+    render_bvh4_kernel now decides per ray whether an empty slot can pass and, if so, walks the tree with constants under
+    which exactly the occupied boxes pass (trav_guard4).  The walk, brute force and the oracle must agree: identical path
+    statistics, images to rounding -- through kernel 4, with the stack the launch plan really allocates."""
+    from flux_amd.procedural import heightfield_mesh
+    from flux_amd.scene import MeshData, MatteData
+    size = 1.0e-4
+    centre = np.array([0.0, 0.0, 0.0]) if where == "tiny_seen_from_afar" else np.array([1.0e3, -2.0e3, 1.5e3])
+    if nx == 0:   # one triangle: wide_stack 0, a one-entry stack
+        v = np.array([[-0.5, -0.4, 0.0], [0.5, -0.3, 0.1], [0.0, 0.5, -0.1]]) * size + centre
+        mesh = MeshData(v, np.array([[0, 1, 2]], dtype=np.uint32), MatteData((0.6, 0.5, 0.4), (0, 0, 0), 0.9))
+    else:
+        mesh = heightfield_mesh(nx, nz, seed=5)
+        # the generator's 28 x 0.7 x 30 field, tilted towards the camera and shrunk to `size`
+        x, y, z = mesh.vertices[:, 0] / 30.0, mesh.vertices[:, 1] / 30.0, (mesh.vertices[:, 2] - 5.0) / 30.0
+        mesh.vertices = np.stack([x, z * 0.8 + y * 4.0, z * -0.6], axis=-1) * size + centre
+    sd = copy.deepcopy(small_scene(demo2, 24, 18))
+    env = copy.deepcopy(next(s for s in sd.shapes if type(s).__name__ == "SphereData" and s.invert))
+    env.center, env.radius = tuple(centre), 1000.0                # the (emissive) environment, around the mesh and the camera
+    sd.shapes = [env, mesh]
+    dist = 300.0
+    sd.camera_settings.eye = tuple(centre + np.array([0.0, 0.0, -dist]))
+    sd.camera_settings.look_at = tuple(centre)
+    sd.camera_data.lens_radius = 0.0
+    sd.camera_data.focal_distance = dist
+    # field of view: 2.5 mesh sizes across the 24 pixels at the mesh's distance
+    sd.camera_data.zoom_factor = 24 * sd.output_settings.pixel_size * dist / (sd.camera_data.view_plane_distance * 2.5 * size)
+    cfg = flux.JobConfiguration(8, 5, 50)
+    o = oracle_mod.Oracle(sd, cfg, seed=6)
+    o.stats(reset=True)
+    want = o.render_frame(threads=8)
+    with flux.Renderer(sd, cfg, seed=6) as r:
+        plan, info = r.launch_plan(), r.bvh_info()
+        assert plan["kernel"] == flux._lib.PLAN_BVH4
+        assert plan["lds"] == max(info["wide_stack"], 1) * 256      # the stack this test must not overrun
+        r.enable_stats(True)
+        out = {}
+        for name, trav in (("wide", flux._lib.TRAVERSE_BVH), ("brute", flux._lib.TRAVERSE_BRUTE)):
+            r.set_traversal(trav)
+            r.stats(reset=True)
+            img = r.render_frame()
+            out[name] = (img, r.stats(reset=True))
+    core = {k: {a: b for a, b in v[1].items() if a not in ("bvh_nodes", "tris_tested")} for k, v in out.items()}
+    assert core["wide"] == core["brute"] == {k: core["brute"][k] for k in core["brute"]}
+    assert {k: core["wide"][k] for k in o.stats()} == o.stats()
+    assert core["wide"]["matte_bounces"] > 24 * 18 * 64 // 20      # the mesh IS hit: a good share of the frame
+    assert out["wide"][1]["bvh_nodes"] > 0
+    assert max_abs_diff(out["wide"][0], out["brute"][0]) < 1e-12
+    assert max_abs_diff(out["wide"][0], want) < 1e-4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nx,nz,n", [(60, 40, 8), (7, 5, 11)])
 def test_wide_and_binary_state_machines_agree(flux, demo2, nx, nz, n):
     """The FAST mesh kernel over the 4-wide tree with quad leaf records (render_bvh4_kernel, the default), the same state
@@ -294,10 +352,12 @@ def test_bvh_stats_and_degenerate_meshes(flux, oracle_mod, demo2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [32, 46, 64])
-def test_high_spp_kernel_configurations(flux, oracle_mod, demo2, n):
-    """Sample counts at which the refill kernel runs 1, 2 and 4 waves per pixel (N >= 1024 per wave) and the BVH
-    kernel stays at one: every combination launches and agrees (BVH == brute force; FAST == STRICT; vs oracle)."""
+@pytest.mark.parametrize("n,waves", [(64, 1), (96, 2), (128, 4)])
+def test_high_spp_kernel_configurations(flux, oracle_mod, demo2, n, waves):
+    """Sample counts at which the refill / split kernels run 1, 2 and 4 waves per pixel (K = the largest power of two with
+    K * FLUX_MIN_SAMPLES_PER_WAVE = K * 4096 <= N: 4096, 9216 and 16384 spp; the launch planner is ASKED, so this test
+    fails if the threshold moves and the counts no longer reach K > 1) while the BVH kernel stays at one: every
+    combination launches and agrees (BVH == brute force; FAST == STRICT; vs oracle)."""
     from flux_amd.procedural import heightfield_scene
     sd = heightfield_scene(6, 4, seed=11, base=small_scene(demo2, 12, 8))
     cfg = flux.JobConfiguration(n, 4, 50)
@@ -307,6 +367,11 @@ def test_high_spp_kernel_configurations(flux, oracle_mod, demo2, n):
             for trav in (flux._lib.TRAVERSE_BVH, flux._lib.TRAVERSE_BRUTE):
                 r.set_math(math)
                 r.set_traversal(trav)
+                plan = r.launch_plan()
+                if math == flux.MATH_FAST and trav == flux._lib.TRAVERSE_BVH:
+                    assert plan["kernel"] == flux._lib.PLAN_BVH4 and plan["waves_per_pixel"] == 1
+                else:  # the refill kernel, with the BVH walk or the brute-force scan inside
+                    assert plan["kernel"] == flux._lib.PLAN_REFILL and plan["waves_per_pixel"] == waves
                 out[(math, trav)] = r.render_frame()
         ref = out[(flux.MATH_STRICT, flux._lib.TRAVERSE_BRUTE)]
         for k, v in out.items():
@@ -315,7 +380,13 @@ def test_high_spp_kernel_configurations(flux, oracle_mod, demo2, n):
     assert max_abs_diff(ref, want) < 1e-4
     plain = small_scene(demo2, 12, 8)  # analytic scene at the same sample counts (1/2/4 waves per pixel)
     with flux.Renderer(plain, cfg, seed=2) as r:
+        assert r.launch_plan()["kernel"] == flux._lib.PLAN_SPLIT and r.launch_plan()["waves_per_pixel"] == waves
         a = r.render_frame()
-        r.set_kernel(flux.KERNEL_STATIC)
+        r.set_kernel(flux.KERNEL_REFILL)
+        assert r.launch_plan()["kernel"] == flux._lib.PLAN_REFILL and r.launch_plan()["waves_per_pixel"] == waves
         assert max_abs_diff(a, r.render_frame()) < 1e-12
-    assert max_abs_diff(a, oracle_mod.Oracle(plain, cfg, seed=2).render_frame(threads=8)) < 1e-4
+        r.set_kernel(flux.KERNEL_STATIC)
+        assert r.launch_plan()["waves_per_pixel"] == 1
+        assert max_abs_diff(a, r.render_frame()) < 1e-12
+    d = np.abs(a - oracle_mod.Oracle(plain, cfg, seed=2).render_frame(threads=8))
+    assert d.max() < 1e-4 and np.percentile(d, 99.9) < 1e-9
