@@ -572,23 +572,34 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
 
 static bool holds_all_sets(const flux_ctx *c) { return c->sets.stride == 1 && c->sets.first == 0; }
 
+// The arithmetic a render really runs with.  FLUX_MATH_FAST is defined for scenes whose surface normals are unit vectors (every
+// sphere; a plane stored with a unit normal): there its closed-form bounce weights and its front-to-back throughput product
+// are the reference's values to rounding.  A plane stored with a NON-unit normal (RenderParams::glossy_long) makes reflected
+// directions non-unit, Phong lobes under- / overflow, and the reference's recursion L = (f (*) L) * s (materials.rs:31-33,
+// 69-71) then meets its zeros and infinities in an order no reordered product reproduces (a 240 000-scene soak: three
+// pixels' channels finite in FAST where the reference holds NaN).  Such a scene is rendered with the
+// STRICT arithmetic, whatever flux_ctx_set_math says: the reference's own operation order, identical in every soak scene.
+static int effective_math(const flux_ctx *ctx) {
+    return (ctx->math == FLUX_MATH_FAST && ctx->rp.glossy_long) ? FLUX_MATH_STRICT : ctx->math;
+}
+
 // LDS one block of the kernel about to be launched needs: asked of the launch plan itself (render_body.inc plan_render_impl:
 // STRICT keeps the (f,s) recursion stack, 4 doubles per level per lane; mesh scenes the BVH traversal stack, one int per
 // level per lane -- 64 lanes in the FAST state-machine kernel, the block's in the others --; the split kernel its path
 // queues), plus the few static words of the refill / split kernels.  64 KiB per block is the launch limit.
 static int check_lds_budget(const flux_ctx *ctx, const flux::RenderParams &p, const char *what) {
-    const size_t dyn = flux::plan_render(p, ctx->variant, ctx->math).lds;
+    const size_t dyn = flux::plan_render(p, ctx->variant, effective_math(ctx)).lds;
     const size_t fixed = 512;
     if (dyn + fixed > 64 * 1024)
         return fail(FLUX_E_INVALID, "%s: %zu B of LDS per block (max_trace_depth %u%s, BVH depth %llu) exceed the 64 KiB limit; "
                     "use FLUX_MATH_FAST or a smaller max_trace_depth", what, dyn + fixed, ctx->D,
-                    ctx->math == FLUX_MATH_STRICT ? " in FLUX_MATH_STRICT: 32 B of recursion stack per level and lane" : "",
+                    effective_math(ctx) == FLUX_MATH_STRICT ? " in the STRICT arithmetic (FLUX_MATH_STRICT, or a scene with a non-unit plane normal): 32 B of recursion stack per level and lane" : "",
                     (unsigned long long)(p.bvh_stack > 0 ? ctx->bvh.max_depth : 0));
     return FLUX_OK;
 }
 // flux_debug_shade: 64-thread blocks, STRICT recursion stack + per-lane BVH stack (render_body.inc launch_shade_rays_impl)
 static int check_lds_budget_rays(const flux_ctx *ctx, const flux::RenderParams &p) {
-    const size_t strict = ctx->math == FLUX_MATH_STRICT ? (size_t)ctx->D * 4 * 64 * sizeof(double) : 0;
+    const size_t strict = effective_math(ctx) == FLUX_MATH_STRICT ? (size_t)ctx->D * 4 * 64 * sizeof(double) : 0;
     const size_t stack = p.n_tris > 0 ? (size_t)p.bvh_stack * 64 * sizeof(int) : 0;
     if (strict + stack > 64 * 1024)
         return fail(FLUX_E_INVALID, "flux_debug_shade: %zu B of LDS per block exceed the 64 KiB limit", strict + stack);
@@ -642,7 +653,7 @@ int flux_debug_shade(flux_ctx *ctx, uint64_t n, const double *rays, uint64_t dep
         return rc;
     }
     if (e == hipSuccess)
-        e = flux::launch_shade_rays(p, ctx->math, d_rays, (int)n, (int)depth, (uint32_t)set_index, (uint32_t)sample_index,
+        e = flux::launch_shade_rays(p, effective_math(ctx), d_rays, (int)n, (int)depth, (uint32_t)set_index, (uint32_t)sample_index,
                                     d_rgb, d_hit, d_t, nullptr);
     if (e == hipSuccess) e = hipMemcpy(out_rgb, d_rgb, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost);
     if (e == hipSuccess && out_hit) e = hipMemcpy(out_hit, d_hit, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
@@ -743,13 +754,14 @@ int flux_ctx_launch_plan(flux_ctx *ctx, uint64_t num_rows, uint64_t num_sets, in
                                          (unsigned long long)held);
         p = sets_params(ctx, ctx->sets.first, ctx->sets.stride, num_sets, nullptr);
     }
-    const flux::LaunchPlan L = flux::plan_render(p, ctx->variant, ctx->math);
+    const flux::LaunchPlan L = flux::plan_render(p, ctx->variant, effective_math(ctx));
     out[0] = L.kernel;
     out[1] = L.block;
     out[2] = (int64_t)L.blocks;
     out[3] = (int64_t)L.lds;
     out[4] = L.waves_per_pixel;
-    out[5] = out[6] = out[7] = 0;
+    out[5] = effective_math(ctx);
+    out[6] = out[7] = 0;
     return FLUX_OK;
 }
 
@@ -772,7 +784,7 @@ int flux_render_rows_device(flux_ctx *ctx, uint64_t first_row, uint64_t row_stri
     const flux::RenderParams p = rows_params(ctx, first_row, row_stride, num_rows, (double *)d_out_rgb);
     if (int rc = check_lds_budget(ctx, p, "flux_render_rows")) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
-    HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
+    HIP_TRY(flux::launch_render(p, ctx->variant, effective_math(ctx), stream));
     HIP_TRY(hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
     return FLUX_OK;
@@ -800,7 +812,7 @@ int flux_render_sets_device(flux_ctx *ctx, uint64_t first_set, uint64_t set_stri
     const flux::RenderParams p = sets_params(ctx, first_set, set_stride, num_sets, (double *)d_out_rgb);
     if (int rc = check_lds_budget(ctx, p, "flux_render_sets_device")) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
-    HIP_TRY(flux::launch_render(p, ctx->variant, ctx->math, stream));
+    HIP_TRY(flux::launch_render(p, ctx->variant, effective_math(ctx), stream));
     HIP_TRY(hipEventRecord(ctx->ev1, stream));
     ctx->timed = true;
     return FLUX_OK;
@@ -869,7 +881,7 @@ int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t *out, uint64_t out_words) {
     w[11] = sizeof(flux::DevNode4Q);
     w[12] = sizeof(flux::DevLeafRec);
     // [13]: asked of the launch planner (a full-frame render with the current variant, arithmetic and traversal)
-    w[13] = flux::plan_render(rows_params(ctx, 0, 1, ctx->H, nullptr), ctx->variant, ctx->math).kernel == FLUX_PLAN_BVH4 ? 1 : 0;
+    w[13] = flux::plan_render(rows_params(ctx, 0, 1, ctx->H, nullptr), ctx->variant, effective_math(ctx)).kernel == FLUX_PLAN_BVH4 ? 1 : 0;
     for (uint64_t k = 0; k < out_words && k < FLUX_BVH_INFO_WORDS; k++) out[k] = w[k];
     return FLUX_OK;
 }

@@ -151,7 +151,7 @@ class Renderer:
         (flux_render_sets_device) when num_sets > 0."""
         buf = (C.c_int64 * _lib.PLAN_WORDS)()
         _lib.check(_lib.lib.flux_ctx_launch_plan(self._handle(), self.height if num_rows is None else num_rows, num_sets, buf))
-        names = ("kernel", "block", "blocks", "lds", "waves_per_pixel")
+        names = ("kernel", "block", "blocks", "lds", "waves_per_pixel", "math")
         return dict(zip(names, [int(x) for x in buf]))
 
     def table(self, which: int) -> np.ndarray:

@@ -202,10 +202,12 @@ int flux_ctx_set_kernel(flux_ctx *ctx, int variant);
  *       division/sqrt/pow/sincos from flux_math.h (<= ~2 ulp), no BoundingBox::hit pre-test (the sphere quadratic
  *       implies its answer, except that a ray with direction.z == 0 whose origin lies on a z face of a sphere's box
  *       misses that sphere -- the box's 0 * inf = NaN, shapes.rs:121-130 -- which is reproduced by an explicit rule),
- *       path throughput multiplied front to back, bounce weights in closed form.  The glossy
- *       closed form (cs ks: the Phong lobe cancels) is used only where the lobe cannot under/overflow, i.e. in scenes
- *       whose plane normals are unit vectors; a scene with a non-unit plane normal gets the reference's long form for
- *       every glossy bounce, so the NaN pixels such a scene has in the reference appear here too;
+ *       path throughput multiplied front to back, bounce weights in closed form (glossy: cs ks, the Phong lobe cancels).
+ *       That is the reference's value to rounding wherever surface normals are unit vectors.  A plane stored with a
+ *       NON-unit normal makes reflected directions non-unit, lobes under- / overflow and the reference's recursion meet
+ *       zeros and infinities in its own order (NaN pixels): a scene that has one is rendered with the STRICT arithmetic
+ *       whatever this setting says, so the reference's NaN pixels appear exactly (flux_ctx_launch_plan reports the
+ *       arithmetic in use);
  *   FLUX_MATH_STRICT: the reference's operation order, no contraction, IEEE division/sqrt, OCML
  *       pow/sincos, BoundingBox::hit before every sphere, (f,s) stack folded deepest bounce first. */
 #define FLUX_MATH_FAST 0
@@ -248,7 +250,9 @@ int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t *out, uint64_t out_words);
  * itself (the library's one launch planner), not a restatement of it: for flux_render_rows* of `num_rows` rows when
  * num_sets == 0, for flux_render_sets_device of `num_sets` sets (all rows) otherwise.
  * out[0] kernel (FLUX_PLAN_*), [1] threads per block, [2] blocks, [3] dynamic LDS bytes per block,
- * [4] waves that share one pixel's samples (K: 1, 2 or 4 -- from the sample count only), [5..7] reserved (0). */
+ * [4] waves that share one pixel's samples (K: 1, 2 or 4 -- from the sample count, and in the STRICT arithmetic the LDS its
+ * recursion stack leaves), [5] the arithmetic the launch runs with (FLUX_MATH_*: STRICT also under FLUX_MATH_FAST when the
+ * scene has a plane with a non-unit normal, see flux_ctx_set_math), [6..7] reserved (0). */
 #define FLUX_PLAN_NONE (-1)    /* nothing to launch */
 #define FLUX_PLAN_STATIC 0     /* render_static_kernel */
 #define FLUX_PLAN_REFILL 1     /* render_refill_kernel */

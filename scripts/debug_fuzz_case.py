@@ -1,5 +1,6 @@
-"""usage: debug_fuzz_case.py <chunk> <case>: re-run one scene of tests/test_gpu_fuzz.py and print oracle vs GPU statistics
-for both arithmetics and all kernels (FLUX_HIP_LIB selects an experiment build)."""
+"""usage: debug_fuzz_case.py <chunk> <case> [old]: re-run one scene of tests/test_gpu_fuzz.py and print oracle vs GPU statistics
+for both arithmetics and all kernels (FLUX_HIP_LIB selects an experiment build).  `old`: the scene as the generator drew it
+before round 4 (plane normals never normalised; the (chunk, case) pairs of round 3's soaks name those)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,7 +12,7 @@ chunk, want_case = int(sys.argv[1]), int(sys.argv[2])
 demo1 = flux.load_scene(os.path.join(ROOT, "scenes", "demo1.yml"))
 rng = np.random.default_rng(1000 + chunk)
 for case in range(40):
-    sd = random_scene(flux, demo1, rng)
+    sd = random_scene(flux, demo1, rng, unit_planes=(case % 2 == 1) and "old" not in sys.argv[3:])
     n = int(rng.choice([1, 2, 3, 8, 9])); D = int(rng.choice([1, 3, 5, 9]))
     seed = int(rng.integers(1, 1 << 30))
     if case != want_case:
