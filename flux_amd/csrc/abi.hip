@@ -389,15 +389,15 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         return code;
     }
     std::vector<flux::DevNodeQ> nodesq;
+    // the FAST traversal kernel's layout: 4-wide nodes + leaf records (flux_bvh.h)
+    std::vector<flux::DevNode4Q> nodes4;
+    std::vector<flux::DevLeafRec> leafrecs;
     flux::build_bvh(tris, nodes, c->bvh);
     if (!flux::quantize_bvh(nodes, nodesq, c->bvh)) {
         int code = fail(FLUX_E_INVALID, "BVH quantisation lost containment (mesh coordinates beyond the 16-bit grid's reach)");
         delete c;
         return code;
     }
-    // the FAST traversal kernel's layout: 4-wide nodes + leaf records (flux_bvh.h)
-    std::vector<flux::DevNode4Q> nodes4;
-    std::vector<flux::DevLeafRec> leafrecs;
     flux::build_wide(nodes, nodesq, tris, nodes4, leafrecs, c->bvh);
     if (nodes4.size() * sizeof(flux::DevNode4Q) >= (1ull << 32) || leafrecs.size() * sizeof(flux::DevLeafRec) >= (1ull << 32) ||
         leafrecs.size() >= (1ull << 28)) {
@@ -463,7 +463,16 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         if (e == hipSuccess) c->device_bytes += bytes;
     };
     alloc((void **)&c->d_shapes, shapes.size() * sizeof(flux::DevShape));
-    alloc((void **)&c->d_mats, mats.size() * sizeof(flux::DevMaterial));
+    // the materials, followed by their bounce weights {f * (n.wi)/pdf in FAST's closed form: f / INV_PI for Matte, f otherwise; pad}
+    // of 32 B each (render_bvh4_kernel keeps a path's material indices and multiplies the weights when the path ends)
+    std::vector<double> wtab(mats.size() * 4, 0.0);
+    for (size_t k = 0; k < mats.size(); k++) {
+        const double sc = mats[k].kind == flux::kMatMatte ? 1.0 / flux::kInvPi : 1.0;
+        wtab[4 * k] = mats[k].fr * sc;
+        wtab[4 * k + 1] = mats[k].fg * sc;
+        wtab[4 * k + 2] = mats[k].fb * sc;
+    }
+    alloc((void **)&c->d_mats, mats.size() * sizeof(flux::DevMaterial) + wtab.size() * sizeof(double));
     alloc((void **)&c->d_fscene, fscene.size());
     alloc((void **)&c->d_pix, pix_bytes);
     alloc((void **)&c->d_disc, pix_bytes);
@@ -487,6 +496,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     }
     if (e == hipSuccess) e = hipMemcpy(c->d_shapes, shapes.data(), shapes.size() * sizeof(flux::DevShape), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_mats, mats.data(), mats.size() * sizeof(flux::DevMaterial), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_mats + mats.size(), wtab.data(), wtab.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_fscene, fscene.data(), fscene.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(c->d_stats, 0, FLUX_NUM_STATS * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
@@ -521,7 +531,9 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.nodes4 = c->d_nodes4;
     rp.leaves = c->d_leaves;
     rp.bvh4_stack = (int32_t)c->bvh.wide_stack;
-    rp.pad_bvh4 = 0;
+    rp.n_mats = (int32_t)mats.size();
+    rp.mat_bits = 1;
+    while ((size_t)1 << rp.mat_bits < mats.size()) rp.mat_bits++;
     for (int a = 0; a < 3; a++) {
         rp.bvh_qmin[a] = c->bvh.qmin[a];
         rp.bvh_qstep[a] = c->bvh.qstep[a];

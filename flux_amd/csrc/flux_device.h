@@ -190,7 +190,7 @@ struct RenderParams {
     // work: rows first_row + k*row_stride, k < num_rows
     double *out;          // [num_rows][W][3]
     int32_t first_row, row_stride, num_rows;
-    int32_t pad;
+    int32_t n_mats;       // records of `mats`; behind them n_mats bounce-weight records of 32 B (abi.hip; render_bvh4_kernel)
     unsigned long long *stats;  // FLUX_NUM_STATS counters or nullptr
     // extension: triangle meshes (0 / nullptr for reference scenes)
     const DevTri *tris;    // leaf order
@@ -200,7 +200,7 @@ struct RenderParams {
     const DevNode4Q *nodes4;   // the 4-wide tree of the FAST traversal kernel (flux_bvh.h), or nullptr
     const DevLeafRec *leaves;  // its leaf records
     int32_t bvh4_stack;        // most entries its per-lane stack can hold at once
-    int32_t pad_bvh4;
+    int32_t mat_bits;          // bits that hold a material index (2^mat_bits >= n_mats)
     int32_t n_tris;
     int32_t bvh_stack;     // per-lane traversal stack entries (= BVH max depth); 0 = brute force
     // FAST path scene (same shapes as `shapes`/`mats`)

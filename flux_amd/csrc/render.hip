@@ -59,7 +59,21 @@
 #define FLUX_BVH4_SORT 0          // render_bvh4_kernel: 1 = hit children fully sorted by entry distance; 0 = only the nearest is singled
 #endif                            //   out and the others stacked as they come (1024 spp: 165.7 -> 159.6 ms; 0.6 % more node visits)
 #ifndef FLUX_WPE_BVH4
-#define FLUX_WPE_BVH4 4           // waves/SIMD of render_bvh4_kernel: 122 VGPRs, no scratch (at 5: 96 VGPRs, 48 spilled, 180 vs 160 ms)
+#define FLUX_WPE_BVH4 5           // waves/SIMD of render_bvh4_kernel: 96 VGPRs, nothing spilled, since round 4's register diet (before: 122 at 4)
+#endif
+#ifndef FLUX_BVH4_WAVE_TOTAL
+#define FLUX_BVH4_WAVE_TOTAL 1    // render_bvh4_kernel: 1 = a pixel's sum is kept per wave in scalar registers (6 VGPRs less, ~75 VALU instructions per shading pass more)
+#endif
+#ifndef FLUX_SPLIT_RELOAD_PARAMS
+#define FLUX_SPLIT_RELOAD_PARAMS 1 // render_split_kernel: kernel arguments re-read (scalar loads) in every pass instead of kept alive across the loop (38 SGPRs spilled to VGPR lanes)
+#endif
+#ifndef FLUX_BVH4_MAT_LIST
+#define FLUX_BVH4_MAT_LIST 0      // render_bvh4_kernel: 1 = a path's throughput as the list of its bounces' materials (1 VGPR, 8 gathers when the path
+                                  // ends: the vector-memory pipeline is what this kernel is short of), 0 = the running product (6 VGPRs).
+                                  // 1 M triangles @4096 spp, one box: list + per-lane sums 572.1, list + wave totals 583.5, product + wave totals 560.5 ms
+#endif
+#ifndef FLUX_BVH4_RELOAD_PARAMS
+#define FLUX_BVH4_RELOAD_PARAMS 1 // render_bvh4_kernel: kernel arguments re-read (scalar loads) in every pass instead of ~64 of them spilled to VGPR lanes
 #endif
 #ifndef FLUX_BVH4_EARLY_REFILL
 #define FLUX_BVH4_EARLY_REFILL 1  // render_bvh4_kernel: the node loop is left for the shading step as soon as FLUX_BVH_REFILL_AT walks have ended

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Compile ONE render kernel (no GPU needed) and print its registers, spills and occupancy -- the quick loop of a register
-diet: ~15 s instead of a full build.  usage: scripts/kernel_regs.py <kernel> [-Dflag ...] [--asm out.s]
+diet: ~15 s instead of a full build.  usage: scripts/kernel_regs.py <kernel> [-Dflag ...] [--asm out.s] [--csrc dir]
    kernel: bvh4 | bvh | split | refill | static   (FAST arithmetic, the product instantiation: no statistics)"""
 import os
 import re
@@ -23,8 +23,13 @@ if "--asm" in args:
     k = args.index("--asm")
     asm_out = args[k + 1]
     del args[k:k + 2]
+csrc = b.CSRC
+if "--csrc" in args:   # another checkout's flux_amd/csrc (A/B against an older kernel)
+    k = args.index("--csrc")
+    csrc = os.path.abspath(args[k + 1])
+    del args[k:k + 2]
 kernel, extra = args[0], args[1:]
-render = open(os.path.join(b.CSRC, "render.hip")).read()
+render = open(os.path.join(csrc, "render.hip")).read()
 head = render[:render.index("// The loop itself lives in render_body.inc")]  # includes + tunables
 src = head + f'''
 #define FLUX_FAST 1
@@ -40,12 +45,12 @@ template __global__ void {INST[kernel]}(const RenderParams);
 '''
 flags = [f for f in b.HIP_FLAGS if f not in ("-shared", "-fPIC")]
 with tempfile.TemporaryDirectory() as td:
-    path = os.path.join(b.CSRC, "_kernel_regs_tmp.hip")
+    path = os.path.join(csrc, "_kernel_regs_tmp.hip")
     open(path, "w").write(src)
     asm = asm_out or os.path.join(td, "k.s")
     try:
         p = subprocess.run([b._hipcc()] + flags + extra + ["-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o", asm, path],
-                           capture_output=True, text=True, cwd=b.CSRC)
+                           capture_output=True, text=True, cwd=csrc)
     finally:
         os.unlink(path)
     if p.returncode:
