@@ -64,6 +64,9 @@
 #ifndef FLUX_BVH4_WAVE_TOTAL
 #define FLUX_BVH4_WAVE_TOTAL 1    // render_bvh4_kernel: 1 = a pixel's sum is kept per wave in scalar registers (6 VGPRs less, ~75 VALU instructions per shading pass more)
 #endif
+#ifndef FLUX_SHADE_TWO_PHASE
+#define FLUX_SHADE_TWO_PHASE 1    // FAST shade_hit: the bounce (and the only update of the loop-carried path state) under ONE `if` after the join of the
+#endif                            //   miss / emitter exits (render_body.inc shade_hit_fast), instead of early returns
 #ifndef FLUX_SPLIT_RELOAD_PARAMS
 #define FLUX_SPLIT_RELOAD_PARAMS 1 // render_split_kernel: kernel arguments re-read (scalar loads) in every pass instead of kept alive across the loop (38 SGPRs spilled to VGPR lanes)
 #endif
