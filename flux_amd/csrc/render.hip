@@ -50,7 +50,7 @@
 #define FLUX_WAVES_PER_EU 3
 #endif
 #ifndef FLUX_WPE_BVH
-#define FLUX_WPE_BVH 5            // waves/SIMD of the BVH traversal kernel
+#define FLUX_WPE_BVH 4            // waves/SIMD of the binary-tree BVH kernel (the fallback): 4 waves, nothing spilled -- at 5 it spills 11 VGPRs
 #endif
 #ifndef FLUX_BVH4_PERM
 #define FLUX_BVH4_PERM 1          // render_bvh4_kernel's slab test: v_perm + magic-number planes + v_pk_fma_f32 (0: rotate + convert)
@@ -67,6 +67,9 @@
 #ifndef FLUX_SHADE_TWO_PHASE
 #define FLUX_SHADE_TWO_PHASE 1    // FAST shade_hit: the bounce (and the only update of the loop-carried path state) under ONE `if` after the join of the
 #endif                            //   miss / emitter exits (render_body.inc shade_hit_fast), instead of early returns
+#ifndef FLUX_RELOAD_PARAMS
+#define FLUX_RELOAD_PARAMS 1      // render_refill_kernel, render_bvh_kernel: the same re-read of the kernel arguments per pass
+#endif
 #ifndef FLUX_SPLIT_RELOAD_PARAMS
 #define FLUX_SPLIT_RELOAD_PARAMS 1 // render_split_kernel: kernel arguments re-read (scalar loads) in every pass instead of kept alive across the loop (38 SGPRs spilled to VGPR lanes)
 #endif
