@@ -1,5 +1,7 @@
-"""Kernel time of ONE rank's share of the frame for G = 1, 2, 4, 8 (row-interleaved shards), measured on a
-single GPU: what each GPU of an N-GPU run executes, without the collective.  usage: shard_time.py [root] [rows|sets]"""
+"""Kernel time of ONE rank's share of the frame for G = 1, 2, 4, 8, measured on a single GPU: what each GPU of an N-GPU run
+executes, without the collective -- EVERY rank's share is rendered and the slowest one counts.  `rows`: row-interleaved
+image tiles (FrameSharder, `bench.py --shard rows`: the north star's tiling and the reference's WorkUnit rows); `sets`:
+sample-set tiles (SetSharder, one pixel per row per owned set).  usage: shard_time.py [root] [rows|sets]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,9 +27,7 @@ for G in (1, 2, 4, 8):
             torch.cuda.synchronize()
             best = min(best, r.last_kernel_ms())
         times.append(best)
-        if G >= 4 and rank >= 1:
-            break  # two ranks are enough to see the spread
     t = max(times)
     base = base or t
-    print(f"{mode} G={G}: slowest measured rank {t:8.2f} ms  ideal {base / G:8.2f} ms  efficiency {base / G / t * 100:5.1f}%  "
+    print(f"{mode} G={G}: slowest of {G} ranks {t:8.2f} ms (fastest {min(times):8.2f})  ideal {base / G:8.2f} ms  efficiency {base / G / t * 100:5.1f}%  "
           f"-> {W * H * n * n / t / 1e3:9.1f} Msamples/s aggregate", flush=True)
