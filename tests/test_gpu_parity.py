@@ -444,3 +444,56 @@ def test_environment_and_self_leaving_shortcuts(flux, oracle_mod, demo2, case, v
         st = r.stats()
     assert {k: st[k] for k in o.stats()} == o.stats()
     assert max_abs_diff(got, want) < TOL_IMAGE
+
+
+def test_fast_means_strict_where_a_plane_normal_is_not_unit(flux, oracle_mod, demo2):
+    """FLUX_MATH_FAST is defined for unit surface normals.  A plane stored with a non-unit normal (the reference never
+    normalises it, shapes.rs:135-152) makes reflected directions non-unit and Phong lobes under- / overflow; the reference's
+    recursion (materials.rs:31-33, 69-71) then meets its zeros and infinities in an order no reordered product reproduces, so
+    the library renders such a scene with the STRICT arithmetic whatever the setting: the launch plan says so, and the FAST
+    and STRICT frames are the same bits.  The same scene with the normal normalised runs the FAST kernels."""
+    import copy
+    sd = copy.deepcopy(small_scene(demo2, 48, 36))
+    plane = next(s for s in sd.shapes if isinstance(s, flux.PlaneData))
+    unit = tuple(float(x) for x in np.array(plane.normal) / np.linalg.norm(plane.normal))
+    cfg = flux.JobConfiguration(16, 5, 50)
+    frames = {}
+    for label, normal in (("unit", unit), ("scaled", tuple(2.5 * x for x in unit))):
+        plane.normal = normal
+        with flux.Renderer(sd, cfg, seed=5) as r:
+            for math in MATH_MODES:
+                r.set_math(_mode(flux, math))
+                plan = r.launch_plan()
+                want_math = flux.MATH_STRICT if (label == "scaled" or math == "strict") else flux.MATH_FAST
+                assert plan["math"] == want_math, (label, math, plan)
+                assert plan["kernel"] == (flux._lib.PLAN_SPLIT if want_math == flux.MATH_FAST else flux._lib.PLAN_REFILL)
+                frames[(label, math)] = r.render_frame()
+        o = oracle_mod.Oracle(sd, cfg, seed=5)
+        want = o.render_frame(threads=8)
+        finite = np.isfinite(want)
+        for math in MATH_MODES:
+            got = frames[(label, math)]
+            assert np.array_equal(np.isfinite(got), finite)
+            assert max_abs_diff(got[finite], want[finite]) < TOL_IMAGE
+    assert np.array_equal(frames[("scaled", "fast")], frames[("scaled", "strict")], equal_nan=True)
+    assert not np.array_equal(frames[("unit", "fast")], frames[("unit", "strict")])   # two arithmetics: equal to rounding only
+    assert max_abs_diff(frames[("unit", "fast")], frames[("unit", "strict")]) < TOL_TIGHT
+
+
+def test_strict_fits_its_waves_per_pixel_to_the_recursion_stack(flux, demo2):
+    """STRICT keeps 32 B of (f, s) recursion stack per level and lane in LDS.  At 16384 spp four waves share a pixel (K = 4,
+    256 lanes): seven levels fit the 64 KiB a block may have.  A deeper job used to be refused; now K falls to what fits (a
+    function of the job alone, so the image still does not depend on the sharding) and the frame equals the static kernel's."""
+    sd = small_scene(demo2, 8, 6)
+    with flux.Renderer(sd, flux.JobConfiguration(128, 9, 50), seed=2) as r:
+        r.set_math(flux.MATH_STRICT)
+        plan = r.launch_plan()
+        assert plan["kernel"] == flux._lib.PLAN_REFILL and plan["waves_per_pixel"] == 2 and plan["lds"] <= 60 * 1024, plan
+        a = r.render_frame()
+        r.set_kernel(flux.KERNEL_STATIC)
+        assert r.launch_plan()["waves_per_pixel"] == 1
+        assert max_abs_diff(a, r.render_frame()) < 1e-12
+        r.set_kernel(flux.KERNEL_DEFAULT)
+        r.set_math(flux.MATH_FAST)            # FAST keeps its throughput in registers: four waves at any depth
+        assert r.launch_plan()["waves_per_pixel"] == 4 and r.launch_plan()["math"] == flux.MATH_FAST
+        assert max_abs_diff(a, r.render_frame()) < TOL_TIGHT
