@@ -70,6 +70,9 @@
 #ifndef FLUX_RELOAD_PARAMS
 #define FLUX_RELOAD_PARAMS 1      // render_refill_kernel, render_bvh_kernel: the same re-read of the kernel arguments per pass
 #endif
+#ifndef FLUX_SPLIT_PIXEL_CONSTS
+#define FLUX_SPLIT_PIXEL_CONSTS 1  // render_split_kernel: primary_ray's per-pixel constants kept in scalar registers
+#endif
 #ifndef FLUX_SPLIT_RELOAD_PARAMS
 #define FLUX_SPLIT_RELOAD_PARAMS 1 // render_split_kernel: kernel arguments re-read (scalar loads) in every pass instead of kept alive across the loop (38 SGPRs spilled to VGPR lanes)
 #endif
@@ -98,7 +101,7 @@
 static_assert(!FLUX_BVH4_EARLY_REFILL || FLUX_BVH4_EARLY_AT >= FLUX_BVH_REFILL_AT,
               "FLUX_BVH4_EARLY_AT must not be below FLUX_BVH_REFILL_AT (render_bvh4_kernel would livelock)");
 #ifndef FLUX_WPE_SPLIT
-#define FLUX_WPE_SPLIT 4          // waves/SIMD of the split kernel (two path states live in phase A)
+#define FLUX_WPE_SPLIT 5          // waves/SIMD of the split kernel: 96 VGPRs, nothing spilled since round 4 (4 until then: 128 VGPRs); demo2 @16384 spp 250.0 -> 225.4 ms
 #endif
 #ifndef FLUX_BVH_LEAF_VOTE
 #define FLUX_BVH_LEAF_VOTE 1      // leave the inner-node loop once the lanes holding a leaf outweigh the descending ones
