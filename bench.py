@@ -190,7 +190,60 @@ def self_launch(n_gpus):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this host driver
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.run(cmd, env=env).returncode
+    # every rank appends the phases it reaches to <dir>/rank<r>.log (phase()): a hang or a dead rank is then reported as
+    # "rank 5 stopped after `ctx created`", never as a silent timeout.  The child is bounded; it is a fresh process, never an exec.
+    import tempfile
+    limit = float(os.environ.get("FLUX_BENCH_LAUNCH_TIMEOUT_S", "900"))
+    with tempfile.TemporaryDirectory(prefix="flux_bench_phases_") as pdir:
+        env["FLUX_BENCH_PHASE_DIR"] = pdir
+        # its own session: on a timeout the WHOLE group goes (the launcher and every rank it started), by exact process group id
+        import signal
+        child = subprocess.Popen(cmd, env=env, start_new_session=True)
+        try:
+            rc = child.wait(timeout=limit)
+            timed_out = False
+        except subprocess.TimeoutExpired:
+            rc, timed_out = 124, True
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(child.pid, sig)
+                except ProcessLookupError:
+                    break
+                try:
+                    child.wait(timeout=10)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+        if rc != 0:
+            print(f"bench.py: the {n_gpus}-rank run {'exceeded ' + str(limit) + ' s' if timed_out else 'exited with code ' + str(rc)}; "
+                  "last phase each rank reached:", file=sys.stderr)
+            for rk in range(n_gpus):
+                try:
+                    with open(os.path.join(pdir, f"rank{rk}.log")) as f:
+                        lines = [ln.strip() for ln in f if ln.strip()]
+                except OSError:
+                    lines = []
+                print(f"  rank {rk}: {lines[-1] if lines else 'never started (no phase recorded)'}", file=sys.stderr)
+    return rc
+
+
+_T_START = time.perf_counter()
+
+
+def phase(rank, world, what):
+    """One line per phase a rank reaches (imported / group up / ctx created / warm-up done / timed / statistics / done): to
+    <FLUX_BENCH_PHASE_DIR>/rank<r>.log when self_launch set it, and to stderr when there is more than one rank (stdout carries
+    the ONE JSON line only)."""
+    line = f"{time.perf_counter() - _T_START:8.2f} s  {what}"
+    d = os.environ.get("FLUX_BENCH_PHASE_DIR")
+    if d:
+        try:
+            with open(os.path.join(d, f"rank{rank}.log"), "a") as f:
+                f.write(line + "\n")
+        except OSError:
+            pass
+    if world > 1:
+        print(f"bench.py rank {rank}/{world}: {line}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -211,6 +264,7 @@ def main():
     import flux_amd
     from flux_amd.dist import FrameSharder, SetSharder, hip_render_fn, hip_render_sets_fn
 
+    phase(rank, world, "imported torch + flux_amd")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the renderer has no CPU fallback)")
     # Rehearsal of the N > 1 path on a one-GPU box (FLUX_BENCH_REHEARSE=1): every rank on device 0, the gather over gloo
@@ -222,10 +276,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # bounded: a rank that never arrives ends the job with an error after two minutes instead of hanging it
+        from datetime import timedelta
+        limit = timedelta(seconds=float(os.environ.get("FLUX_BENCH_GROUP_TIMEOUT_S", "120")))
         if rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
+        phase(rank, world, f"process group up ({dist.get_backend()})")
 
     if a.scene.startswith("hf:"):  # BASELINE config 5: procedural height field, e.g. hf:1000x500 = 1M triangles
         from flux_amd.procedural import heightfield_scene
@@ -247,6 +305,7 @@ def main():
     r = flux_amd.Renderer(sd, cfg, seed=a.seed, device=local_rank, set_share=(rank, world) if use_sets else None)
     torch.cuda.synchronize()
     t_create = time.perf_counter() - t0
+    phase(rank, world, f"ctx created ({t_create * 1e3:.0f} ms)")
     r.set_kernel(a.kernel)
     r.set_math(flux_amd.MATH_FAST if a.math == "fast" else flux_amd.MATH_STRICT)
     if use_sets:
@@ -265,6 +324,7 @@ def main():
     for _ in range(a.warmup):
         frame = sh.step(fn)
     barrier()
+    phase(rank, world, f"warm-up done ({a.warmup} steps)")
     # HIP events on the stream the kernel is launched on (torch's current stream: hip_render_*_fn passes it down, and
     # there is ONE HIP runtime in the process, flux_amd/_lib.py): render | all_gather | reassembly, per step
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(a.steps)]
@@ -281,10 +341,25 @@ def main():
     elapsed = time.perf_counter() - t0
     phases = [sum(e[j].elapsed_time(e[j + 1]) for e in ev) / max(a.steps, 1) for j in range(3)]
 
-    t = torch.tensor([elapsed] + phases, dtype=torch.float64, device=dev)
+    phase(rank, world, f"timed {a.steps} steps ({elapsed / max(a.steps, 1) * 1e3:.2f} ms per step here)")
+
+    # every rank's own numbers (manager.rs:145,156-170: the reference's timer spans the slowest worker; here each rank's share is
+    # kept so that a slow rank, a slow gather or a slow Python launch path can be told apart): one all_gather of 5 doubles
+    t = torch.tensor([elapsed] + phases + [elapsed / max(a.steps, 1) * 1e3 - sum(phases)], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_max, kernel_ms_max, gather_ms_max, assemble_ms_max = [float(x) for x in t]
+        from flux_amd.dist import _all_gather
+        allt = torch.empty((world, t.numel()), dtype=torch.float64, device=dev)
+        _all_gather(allt, t)  # (over gloo -- the one-GPU rehearsal -- through the host)
+    else:
+        allt = t.reshape(1, -1)
+    allt = allt.cpu()
+    elapsed_max, kernel_ms_max, gather_ms_max, assemble_ms_max, overhead_ms_max = [float(x) for x in allt.max(dim=0).values]
+    per_rank = [{"rank": k, "wall_ms_per_step": round(float(allt[k, 0]) / max(a.steps, 1) * 1e3, 3), "render": round(float(allt[k, 1]), 3),
+                 "all_gather": round(float(allt[k, 2]), 3), "reassembly": round(float(allt[k, 3]), 3),
+                 "launch_overhead_ms": round(float(allt[k, 4]), 3)} for k in range(world)]
+    spread = {name: {"min": round(float(allt[:, j].min()), 3), "mean": round(float(allt[:, j].mean()), 3),
+                     "max": round(float(allt[:, j].max()), 3)}
+              for j, name in ((1, "render"), (2, "all_gather"), (3, "reassembly"), (4, "launch_overhead_ms"))}
 
     # what HBM delivers on THIS device ("report against both" the 8 TB/s spec and a measured copy): a 1 GiB
     # device-to-device copy, read + write bytes, best of 5 (untimed extra)
@@ -311,6 +386,7 @@ def main():
     torch.cuda.synchronize()
     st = r.stats(reset=True)
     r.enable_stats(False)
+    phase(rank, world, "statistics pass done")
     stt = torch.tensor([st["samples"], st["matte_bounces"], st["segments"], st["glossy_bounces"], st["bvh_nodes"],
                         st["tris_tested"], st["misses"]], dtype=torch.float64, device=dev)
     if world > 1:
@@ -403,7 +479,11 @@ def main():
                        **({"rehearsal": "all ranks on ONE GPU, gather over gloo: not a measurement"} if rehearse else {})},
             "step_breakdown_ms": {"render": round(kernel_ms_max, 3), "all_gather": round(gather_ms_max, 3),
                                   "reassembly": round(assemble_ms_max, 3),
-                                  "note": "HIP events on the launch stream, mean over steps, max over ranks"},
+                                  "launch_overhead_ms": round(overhead_ms_max, 3),
+                                  "spread_over_ranks": spread, "per_rank": per_rank,
+                                  "note": "HIP events on the launch stream, mean over steps; render / all_gather / reassembly at the top "
+                                          "level are the max over ranks; launch_overhead_ms = a rank's wall time per step minus its three "
+                                          "event spans (host-side launch path, event gaps, the barrier wait for slower ranks)"},
             "roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "basis": basis,
@@ -463,6 +543,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    phase(rank, world, "done")
 
 
 if __name__ == "__main__":

@@ -398,7 +398,14 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         delete c;
         return code;
     }
+#if FLUX_BVH4_ARENA
+    // round 5: nodes and leaf records in ONE arena of 64-B units, a node's children contiguous (flux_bvh.h DevNode4A); an
+    // arena beyond the 26-bit unit index comes back empty and the mesh is walked by the binary tree's kernel
+    std::vector<flux::DevNode4A> arena;
+    flux::build_wide_arena(nodes, nodesq, tris, arena, c->bvh);
+#else
     flux::build_wide(nodes, nodesq, tris, nodes4, leafrecs, c->bvh);
+#endif
     if (nodes4.size() * sizeof(flux::DevNode4Q) >= (1ull << 32) || leafrecs.size() * sizeof(flux::DevLeafRec) >= (1ull << 32) ||
         leafrecs.size() >= (1ull << 28)) {
         int code = fail(FLUX_E_INVALID, "mesh too large for the traversal kernel's 32-bit record offsets");
@@ -488,11 +495,18 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         if (e == hipSuccess) e = hipMemcpy(c->d_nodes, nodes.data(), nodes.size() * sizeof(flux::DevNode), hipMemcpyHostToDevice);
         alloc((void **)&c->d_nodesq, nodesq.size() * sizeof(flux::DevNodeQ));
         if (e == hipSuccess) e = hipMemcpy(c->d_nodesq, nodesq.data(), nodesq.size() * sizeof(flux::DevNodeQ), hipMemcpyHostToDevice);
+#if FLUX_BVH4_ARENA
+        if (!arena.empty()) {
+            alloc((void **)&c->d_nodes4, arena.size() * sizeof(flux::DevNode4A));
+            if (e == hipSuccess) e = hipMemcpy(c->d_nodes4, arena.data(), arena.size() * sizeof(flux::DevNode4A), hipMemcpyHostToDevice);
+        }
+#else
         alloc((void **)&c->d_nodes4, nodes4.size() * sizeof(flux::DevNode4Q));
         if (e == hipSuccess) e = hipMemcpy(c->d_nodes4, nodes4.data(), nodes4.size() * sizeof(flux::DevNode4Q), hipMemcpyHostToDevice);
         alloc((void **)&c->d_leaves, (leafrecs.size() + 1) * sizeof(flux::DevLeafRec));
         if (e == hipSuccess && !leafrecs.empty())
             e = hipMemcpy(c->d_leaves, leafrecs.data(), leafrecs.size() * sizeof(flux::DevLeafRec), hipMemcpyHostToDevice);
+#endif
     }
     if (e == hipSuccess) e = hipMemcpy(c->d_shapes, shapes.data(), shapes.size() * sizeof(flux::DevShape), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_mats, mats.data(), mats.size() * sizeof(flux::DevMaterial), hipMemcpyHostToDevice);

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <limits>
 
 #ifndef FLUX_BVH_BINS
@@ -283,9 +284,23 @@ void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &
     tris.swap(sorted);
     info.nodes = nodes.size();
     info.mag = mag;
+    info.pad = pad;
     info.build_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(
                         std::chrono::steady_clock::now() - t0).count();
 }
+
+namespace {
+uint16_t grid_lo(const BvhInfo &info, float v, int a) {  // a grid point at least one quantum below v
+    if (!std::isfinite(v)) return v > 0 ? 65535 : 0;
+    double q = std::floor(((double)v - (double)info.qmin[a]) / (double)info.qstep[a]) - 1.0;
+    return (uint16_t)std::min(std::max(q, 0.0), 65535.0);
+}
+uint16_t grid_hi(const BvhInfo &info, float v, int a) {  // a grid point at least one quantum above v
+    if (!std::isfinite(v)) return v > 0 ? 65535 : 0;
+    double q = std::ceil(((double)v - (double)info.qmin[a]) / (double)info.qstep[a]) + 1.0;
+    return (uint16_t)std::min(std::max(q, 0.0), 65535.0);
+}
+}  // namespace
 
 bool quantize_bvh(const std::vector<DevNode> &nodes, std::vector<DevNodeQ> &out, BvhInfo &info) {
     out.clear();
@@ -327,16 +342,8 @@ bool quantize_bvh(const std::vector<DevNode> &nodes, std::vector<DevNodeQ> &out,
         info.qstep[a] = st;
         info.qmin[a] = org;
     }
-    auto qlo = [&](float v, int a) -> uint16_t {  // a grid point at least one quantum below v
-        if (!std::isfinite(v)) return v > 0 ? 65535 : 0;
-        double q = std::floor(((double)v - (double)info.qmin[a]) / (double)info.qstep[a]) - 1.0;
-        return (uint16_t)std::min(std::max(q, 0.0), 65535.0);
-    };
-    auto qhi = [&](float v, int a) -> uint16_t {  // a grid point at least one quantum above v
-        if (!std::isfinite(v)) return v > 0 ? 65535 : 0;
-        double q = std::ceil(((double)v - (double)info.qmin[a]) / (double)info.qstep[a]) + 1.0;
-        return (uint16_t)std::min(std::max(q, 0.0), 65535.0);
-    };
+    auto qlo = [&](float v, int a) { return grid_lo(info, v, a); };
+    auto qhi = [&](float v, int a) { return grid_hi(info, v, a); };
     out.resize(nodes.size());
     for (size_t k = 0; k < nodes.size(); k++) {
         const DevNode &N = nodes[k];
@@ -534,6 +541,237 @@ void build_wide(const std::vector<DevNode> &nodes, const std::vector<DevNodeQ> &
     }
     info.wide_nodes = wide.size();
     info.leaf_records = leaves.size();
+    info.wide_stack = need[0];
+}
+
+
+// ---- the arena layout (flux_bvh.h DevNode4A): children contiguous, ONE stack entry per node ------------------------------
+void build_wide_arena(const std::vector<DevNode> &nodes, const std::vector<DevNodeQ> &nodesq, const std::vector<DevTri> &tris,
+                      std::vector<DevNode4A> &arena, BvhInfo &info) {
+    arena.clear();
+    info.wide_nodes = info.leaf_records = info.fused_leaves = info.wide_stack = info.arena_units = info.split_leaves = 0;
+    if (nodes.empty()) return;
+    constexpr int32_t kEmpty = INT32_MIN;
+    // (1) the binary tree with its leaves rewritten: a leaf link becomes ~record (ONE record: a quad's two halves or a single
+    //     triangle); a leaf whose triangles need more than one record becomes a small subtree of one-record leaves, boxes from
+    //     the triangles themselves (f32, rounded outward and padded like every box; on the same 16-bit grid)
+    std::vector<DevNode> bn = nodes;
+    std::vector<DevNodeQ> bq = nodesq;
+    std::vector<DevLeafRec> recs;
+    struct FBox { float lo[3], hi[3]; };
+    auto rec_box = [&](const DevLeafRec &R) {
+        double lo[3], hi[3];
+        for (int a = 0; a < 3; a++) {
+            const double v0 = R.v0[a], v1 = R.v0[a] + R.e1[a], v2 = R.v0[a] + R.e2[a];
+            lo[a] = std::min(v0, std::min(v1, v2));
+            hi[a] = std::max(v0, std::max(v1, v2));
+            if (R.slot[1] >= 0) {
+                const double v3 = R.v0[a] + R.e3[a];
+                lo[a] = std::min(lo[a], v3);
+                hi[a] = std::max(hi[a], v3);
+            }
+        }
+        FBox b;
+        for (int a = 0; a < 3; a++) {
+            b.lo[a] = Builder::down(lo[a] - info.pad);
+            b.hi[a] = Builder::up(hi[a] + info.pad);
+        }
+        return b;
+    };
+    auto same3 = [](double ax, double ay, double az, double bx, double by, double bz) { return ax == bx && ay == by && az == bz; };
+    auto single = [&](int k) {
+        const DevTri &T = tris[(size_t)k];
+        DevLeafRec R;
+        std::memset(&R, 0, sizeof(R));
+        R.v0[0] = T.v0x; R.v0[1] = T.v0y; R.v0[2] = T.v0z;
+        R.e1[0] = T.e1x; R.e1[1] = T.e1y; R.e1[2] = T.e1z;
+        R.e2[0] = T.e2x; R.e2[1] = T.e2y; R.e2[2] = T.e2z;
+        R.id[0] = T.id; R.id[1] = -1;
+        R.slot[0] = k; R.slot[1] = -1;
+        recs.push_back(R);
+    };
+    auto leaf_records = [&](int first, int cnt) {  // the records of triangles [first, first + cnt): quads where two fuse
+        int k = 0;
+        while (k < cnt) {
+            bool fused = false;
+            if (k + 1 < cnt) {
+                const DevTri &A = tris[(size_t)(first + k)], &B = tris[(size_t)(first + k + 1)];
+                if (same3(A.v0x, A.v0y, A.v0z, B.v0x, B.v0y, B.v0z)) {
+                    const DevTri *X = nullptr, *Y = nullptr;  // X = (v0, e1, e2), Y = (v0, e2, e3)
+                    int sx = 0, sy = 0;
+                    if (same3(A.e2x, A.e2y, A.e2z, B.e1x, B.e1y, B.e1z)) { X = &A; Y = &B; sx = first + k; sy = first + k + 1; }
+                    else if (same3(B.e2x, B.e2y, B.e2z, A.e1x, A.e1y, A.e1z)) { X = &B; Y = &A; sx = first + k + 1; sy = first + k; }
+                    if (X) {
+                        DevLeafRec R;
+                        std::memset(&R, 0, sizeof(R));
+                        R.v0[0] = X->v0x; R.v0[1] = X->v0y; R.v0[2] = X->v0z;
+                        R.e1[0] = X->e1x; R.e1[1] = X->e1y; R.e1[2] = X->e1z;
+                        R.e2[0] = X->e2x; R.e2[1] = X->e2y; R.e2[2] = X->e2z;
+                        R.e3[0] = Y->e2x; R.e3[1] = Y->e2y; R.e3[2] = Y->e2z;
+                        R.id[0] = X->id; R.id[1] = Y->id;
+                        R.slot[0] = sx; R.slot[1] = sy;
+                        recs.push_back(R);
+                        info.fused_leaves++;
+                        fused = true;
+                        k += 2;
+                    }
+                }
+            }
+            if (!fused) {
+                single(first + k);
+                k++;
+            }
+        }
+    };
+    // subtree over records [lo, hi), hi - lo >= 2: halves; returns the new node's index
+    std::function<int32_t(int, int)> subtree = [&](int lo, int hi) -> int32_t {
+        const int32_t me = (int32_t)bn.size();
+        bn.emplace_back();
+        bq.emplace_back();
+        const int mid = lo + (hi - lo) / 2;
+        const int rb[2] = {lo, mid}, re[2] = {mid, hi};
+        for (int side = 0; side < 2; side++) {
+            FBox b;
+            for (int a = 0; a < 3; a++) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+            for (int r = rb[side]; r < re[side]; r++) {
+                const FBox t = rec_box(recs[(size_t)r]);
+                for (int a = 0; a < 3; a++) { b.lo[a] = std::min(b.lo[a], t.lo[a]); b.hi[a] = std::max(b.hi[a], t.hi[a]); }
+            }
+            const int32_t link = re[side] - rb[side] == 1 ? ~(int32_t)rb[side] : subtree(rb[side], re[side]);
+            DevNode &N = bn[(size_t)me];  // re-fetch: the vectors may have grown
+            DevNodeQ &Q = bq[(size_t)me];
+            float *nlo = side ? N.lo1 : N.lo0, *nhi = side ? N.hi1 : N.hi0;
+            uint16_t *qlo = side ? Q.lo1 : Q.lo0, *qhi = side ? Q.hi1 : Q.hi0;
+            for (int a = 0; a < 3; a++) {
+                nlo[a] = b.lo[a];
+                nhi[a] = b.hi[a];
+                qlo[a] = grid_lo(info, b.lo[a], a);
+                qhi[a] = grid_hi(info, b.hi[a], a);
+            }
+            (side ? N.child1 : N.child0) = link;
+            (side ? Q.child1 : Q.child0) = link;
+            (side ? N.count1 : N.count0) = 0;
+        }
+        return me;
+    };
+    const size_t n_orig = nodes.size();
+    for (size_t k = 0; k < n_orig; k++)
+        for (int side = 0; side < 2; side++) {
+            const int32_t link = side ? nodes[k].child1 : nodes[k].child0;
+            if (link >= 0) continue;
+            const int ref = ~link, first = ref >> 3, cnt = ref & 7;
+            int32_t nl = kEmpty;  // (the one-leaf tree's second slot: an empty leaf)
+            if (cnt > 0) {
+                const int r0 = (int)recs.size();
+                leaf_records(first, cnt);
+                const int r1 = (int)recs.size();
+                if (r1 - r0 == 1) nl = ~(int32_t)r0;
+                else {
+                    nl = subtree(r0, r1);
+                    info.split_leaves++;
+                }
+            }
+            (side ? bn[k].child1 : bn[k].child0) = nl;
+            (side ? bq[k].child1 : bq[k].child0) = nl;
+        }
+    // (2) collapse by surface area as build_wide does, breadth-first; (3) lay the children of every node out contiguously
+    struct Slot {
+        int32_t link;  // >= 0 binary node, < 0 ~record
+        uint16_t lo[3], hi[3];
+        float area;
+    };
+    auto slot_of = [&](int32_t parent, int side) {
+        const DevNode &N = bn[(size_t)parent];
+        const DevNodeQ &Q = bq[(size_t)parent];
+        Slot s;
+        s.link = side ? N.child1 : N.child0;
+        const float *lo = side ? N.lo1 : N.lo0, *hi = side ? N.hi1 : N.hi0;
+        for (int a = 0; a < 3; a++) {
+            s.lo[a] = side ? Q.lo1[a] : Q.lo0[a];
+            s.hi[a] = side ? Q.hi1[a] : Q.hi0[a];
+        }
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        s.area = (dx >= 0 && dy >= 0 && dz >= 0) ? 2.0f * (dx * dy + dy * dz + dz * dx) : -1.0f;
+        return s;
+    };
+    struct Item { int32_t b; uint32_t unit; };
+    std::vector<Item> queue;
+    std::vector<std::array<uint32_t, 4>> kid_items;  // per queue entry: queue index of each inner child (for the stack bound)
+    std::vector<int> kid_count, inner_count;
+    queue.push_back(Item{0, 0u});
+    arena.resize(2);  // the root and one unit of padding: blocks start on even units
+    std::memset(arena.data(), 0, 2 * sizeof(DevNode4A));
+    bool too_large = false;
+    for (size_t head = 0; head < queue.size() && !too_large; head++) {
+        const int32_t b = queue[head].b;
+        Slot sl[4];
+        int n = 0;
+        for (int side = 0; side < 2; side++) {
+            const Slot s = slot_of(b, side);
+            if (s.link != kEmpty) sl[n++] = s;
+        }
+        while (n < 4) {  // open the inner child with the largest surface
+            int pick = -1;
+            for (int k = 0; k < n; k++)
+                if (sl[k].link >= 0 && (pick < 0 || sl[k].area > sl[pick].area)) pick = k;
+            if (pick < 0) break;
+            const int32_t c = sl[pick].link;
+            const Slot s0 = slot_of(c, 0), s1 = slot_of(c, 1);
+            n--;
+            for (int k = pick; k < n; k++) sl[k] = sl[k + 1];
+            if (s0.link != kEmpty) sl[n++] = s0;
+            if (s1.link != kEmpty) sl[n++] = s1;
+        }
+        std::stable_sort(sl, sl + n, [](const Slot &x, const Slot &y) { return (x.link >= 0) > (y.link >= 0); });
+        int n_in = 0;
+        while (n_in < n && sl[n_in].link >= 0) n_in++;
+        const size_t start = (arena.size() + 1) & ~(size_t)1;
+        const size_t leaf0 = start + (size_t)((n_in + 1) & ~1);
+        const size_t end = n > n_in ? leaf0 + 2 * (size_t)(n - n_in) : start + (size_t)n_in;
+        if (end >= ((size_t)1 << 26)) { too_large = true; break; }
+        arena.resize(end);
+        for (size_t u = start; u < end; u++) std::memset(&arena[u], 0, sizeof(DevNode4A));
+        DevNode4A W;
+        std::memset(&W, 0, sizeof(W));
+        std::array<uint32_t, 4> kids_q = {0, 0, 0, 0};
+        for (int k = 0; k < 4; k++) {
+            if (k < n) {
+                const Slot &S = sl[k];
+                W.bx[k] = (uint32_t)S.lo[0] | ((uint32_t)S.hi[0] << 16);
+                W.by[k] = (uint32_t)S.lo[1] | ((uint32_t)S.hi[1] << 16);
+                W.bz[k] = (uint32_t)S.lo[2] | ((uint32_t)S.hi[2] << 16);
+                if (S.link >= 0) {
+                    kids_q[(size_t)k] = (uint32_t)queue.size();
+                    queue.push_back(Item{S.link, (uint32_t)(start + (size_t)k)});
+                } else {
+                    std::memcpy(&arena[leaf0 + 2 * (size_t)(k - n_in)], &recs[(size_t)~S.link], sizeof(DevLeafRec));
+                    info.leaf_records++;
+                }
+            } else {
+                W.bx[k] = W.by[k] = W.bz[k] = 0x0000ffffu;  // lo 65535, hi 0: never hit
+            }
+        }
+        W.meta = ((uint32_t)n_in << 4) | ((uint32_t)(start >> 1) << 7);
+        W.kids = (uint32_t)n;
+        arena[queue[head].unit] = W;
+        kid_items.push_back(kids_q);
+        kid_count.push_back(n);
+        inner_count.push_back(n_in);
+    }
+    if (too_large) {  // beyond the 26-bit unit index of a stack entry: the caller falls back to the binary tree's kernel
+        arena.clear();
+        info.leaf_records = 0;
+        return;
+    }
+    // most stack entries at once: a visit of a node with two children or more leaves at most ONE entry behind
+    std::vector<uint32_t> need(queue.size(), 0);
+    for (size_t w = queue.size(); w-- > 0;) {  // children come later in the queue: bottom-up
+        uint32_t deepest = 0;
+        for (int k = 0; k < inner_count[w]; k++) deepest = std::max(deepest, need[(size_t)kid_items[w][(size_t)k]]);
+        need[w] = (kid_count[w] >= 2 ? 1u : 0u) + deepest;
+    }
+    info.wide_nodes = queue.size();
+    info.arena_units = arena.size();
     info.wide_stack = need[0];
 }
 

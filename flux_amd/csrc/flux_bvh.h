@@ -67,6 +67,40 @@ struct DevLeafRec {
 };
 static_assert(sizeof(DevLeafRec) == 128, "DevLeafRec layout");
 
+// ---- round 5: ONE stack entry per NODE instead of one per deferred child (FLUX_BVH4_ARENA = 1, the default) ---------------
+// The per-lane LDS stack of the link layout above holds one entry per hit-but-deferred CHILD, so its bound is the sum of
+// (children - 1) along a path: 32 entries = 8 KiB per wave on the 1 M-triangle field, 7 LDS granules of 1 280 B, 18 waves per
+// CU instead of the 20 the kernel's registers allow.  Here a node's children are CONTIGUOUS in one arena of 64-B units --
+// inner children first (one unit each), then the leaf records (two units each, 128-B aligned) -- so a child's link is
+// arithmetic on (first unit, slot) and ONE 32-bit entry per node, `first | number of inner children | mask of the pending
+// slots`, replaces up to three: the bound drops to the number of nodes with >= 2 children on a path (the wide tree's depth).
+//   unit 0: the root; its children block starts at unit 2 (blocks start on even units).
+//   leaf child = exactly ONE record: a binary leaf whose two triangles do not fuse into a quad becomes a node of its own
+//   with two one-triangle leaves (boxes from the triangles, on the same grid).
+struct DevNode4A {
+    uint32_t bx[4], by[4], bz[4];  // as DevNode4Q; slots sorted: inner children, leaf children, empty slots (lo 65535, hi 0)
+    uint32_t meta;                 // bits 0-3: 0 (the pending mask of a stack entry), 4-6: inner children, 7-31: first child unit >> 1
+    uint32_t kids;                 // occupied slots (host-side checks; the device reads `meta` only)
+    uint32_t pad[2];
+};
+static_assert(sizeof(DevNode4A) == 64, "DevNode4A layout");
+// link of slot k of a node / stack entry e: >= 0 the unit of an inner node, < 0: ~(unit of a leaf record)
+#ifdef __HIP__  // (hipcc compiles bvh.cpp as HIP too, without hip_runtime.h: attributes spelled out)
+#define FLUX_BVH_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define FLUX_BVH_HD inline
+#endif
+// (written without a branch: inner child f + k, leaf record ~(f + 2k - (n & 6)): the leaf's extra term and the complement are
+// applied under an all-ones mask -- the device compiler turned the plain ternary into two exec-masked blocks per visit)
+FLUX_BVH_HD int32_t wide_link(uint32_t e, uint32_t k) {
+    const uint32_t t = e >> 4, n = t & 7u, f = (e >> 6) & ~1u;
+    const uint32_t leaf = k >= n ? 0xffffffffu : 0u;
+    return (int32_t)((f + k + ((k - (t & 6u)) & leaf)) ^ leaf);
+}
+#ifndef FLUX_BVH4_ARENA
+#define FLUX_BVH4_ARENA 1
+#endif
+
 constexpr int kBvhSahDepth = 32;    // below this depth the builder uses SAH, deeper: median splits
 constexpr int kBvhMaxDepth = 64;    // hard limit; the per-lane LDS stack is sized max_depth entries
 #ifndef FLUX_BVH_LEAF
@@ -79,7 +113,10 @@ struct BvhInfo {
     double mag = 0.0;  // largest |coordinate| of any vertex (scale of the f32 slab test's padding)
     float qmin[3] = {0, 0, 0}, qstep[3] = {1, 1, 1};  // the 16-bit grid of DevNodeQ: coordinate = qmin + q * qstep
     uint64_t wide_nodes = 0, leaf_records = 0, fused_leaves = 0;
-    uint64_t wide_stack = 0;  // most entries the 4-wide traversal can have stacked at once (sum of children - 1 along a path)
+    uint64_t wide_stack = 0;  // most entries the 4-wide traversal can have stacked at once (link layout: sum of children - 1
+                              // along a path; arena layout: nodes with two children or more along a path)
+    double pad = 0.0;         // absolute padding of every f32 box (build_bvh)
+    uint64_t arena_units = 0, split_leaves = 0;  // arena layout: 64-B units; binary leaves that became a node of one-triangle leaves
 };
 
 // Binned-SAH top-down build.  `tris` is reordered into leaf order (ids keep the original order).
@@ -92,5 +129,9 @@ bool quantize_bvh(const std::vector<DevNode> &nodes, std::vector<DevNodeQ> &out,
 // The 4-wide tree + leaf records of the FAST traversal kernel from the binary tree and its quantised boxes.
 void build_wide(const std::vector<DevNode> &nodes, const std::vector<DevNodeQ> &nodesq, const std::vector<DevTri> &tris,
                 std::vector<DevNode4Q> &wide, std::vector<DevLeafRec> &leaves, BvhInfo &info);
+
+// The same tree in the arena layout (DevNode4A above): `arena` holds nodes (1 unit) and leaf records (2 units) in 64-B units.
+void build_wide_arena(const std::vector<DevNode> &nodes, const std::vector<DevNodeQ> &nodesq, const std::vector<DevTri> &tris,
+                      std::vector<DevNode4A> &arena, BvhInfo &info);
 
 }  // namespace flux

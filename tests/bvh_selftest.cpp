@@ -177,7 +177,82 @@ static void check_mesh(const char *name, std::vector<DevTri> tris) {
     for (size_t k = 0; k < L.size(); k++) CHECK(rec_seen[k] == 1, "%s: leaf record %zu reached %d times", name, k, rec_seen[k]);
     for (size_t k = 0; k < n; k++) CHECK(slot_seen[k] == 1, "%s: DevTri slot %zu in %d records", name, k, slot_seen[k]);
     CHECK(max_stack <= info.wide_stack, "%s: stack bound %llu < %llu", name, (unsigned long long)info.wide_stack, (unsigned long long)max_stack);
+    // the arena layout (round 5): children contiguous, one record per leaf child, ONE stack entry per node
+    {
+        std::vector<DevNode4A> A;
+        BvhInfo ia = info;
+        build_wide_arena(nodes, q, tris, A, ia);
+        CHECK(ia.arena_units == A.size() && A.size() >= 2, "%s: arena size", name);
+        std::vector<int> unit_used(A.size(), 0), slot2(n, 0);
+        uint64_t max_entries = 0, n_nodes = 0, n_recs = 0;
+        std::function<void(uint32_t, uint64_t, int)> awalk = [&](uint32_t unit, uint64_t stacked, int depth) {
+            CHECK(unit < A.size(), "%s: arena unit out of range", name);
+            CHECK(depth <= 64, "%s: arena depth", name);
+            if (unit >= A.size() || depth > 64) return;
+            const DevNode4A &W = A[unit];
+            unit_used[unit]++;
+            n_nodes++;
+            const uint32_t n_in = (W.meta >> 4) & 7u, first = (W.meta >> 6) & ~1u;
+            CHECK((W.meta & 15u) == 0u, "%s: meta's mask bits", name);
+            CHECK(W.kids >= 1 && W.kids <= 4 && n_in <= W.kids, "%s: arena node %u: kids %u inner %u", name, unit, W.kids, n_in);
+            CHECK(first > unit && (first & 1u) == 0u, "%s: children block of %u at %u", name, unit, first);
+            const uint64_t here = stacked + (W.kids >= 2 ? 1 : 0);
+            if (here > max_entries) max_entries = here;
+            for (uint32_t k = 0; k < 4; k++) {
+                if (k >= W.kids) {
+                    CHECK(W.bx[k] == 0x0000ffffu && W.by[k] == 0x0000ffffu && W.bz[k] == 0x0000ffffu, "%s: arena empty slot's box", name);
+                    continue;
+                }
+                CHECK((W.bx[k] & 0xffffu) <= (W.bx[k] >> 16) && (W.by[k] & 0xffffu) <= (W.by[k] >> 16) && (W.bz[k] & 0xffffu) <= (W.bz[k] >> 16), "%s: arena inverted child box", name);
+                // a stack entry with any pending mask yields the same links as the node's own meta word
+                const int32_t link = wide_link(W.meta, k);
+                CHECK(link == wide_link(W.meta | 15u, k) && link == wide_link(W.meta | (1u << k), k), "%s: wide_link depends on the mask", name);
+                if (k < n_in) {
+                    CHECK(link == (int32_t)(first + k), "%s: inner link", name);
+                    awalk((uint32_t)link, here, depth + 1);
+                } else {
+                    CHECK(link < 0, "%s: leaf link", name);
+                    const uint32_t ru = (uint32_t)~link;
+                    CHECK(ru + 1 < A.size() && (ru & 1u) == 0u, "%s: leaf record unit %u", name, ru);
+                    if (ru + 1 >= A.size()) continue;
+                    unit_used[ru]++;
+                    unit_used[ru + 1]++;
+                    n_recs++;
+                    DevLeafRec R;
+                    std::memcpy(&R, &A[ru], sizeof(R));
+                    for (int half = 0; half < 2; half++) {
+                        const int sl = R.slot[half];
+                        if (sl < 0) { CHECK(half == 1, "%s: arena record without triangle A", name); continue; }
+                        CHECK((size_t)sl < n, "%s: arena record slot", name);
+                        if ((size_t)sl >= n) continue;
+                        slot2[(size_t)sl]++;
+                        const DevTri &T = tris[(size_t)sl];
+                        CHECK(R.id[half] == T.id, "%s: arena record id", name);
+                        const double *ea = half ? R.e2 : R.e1, *eb = half ? R.e3 : R.e2;
+                        CHECK(R.v0[0] == T.v0x && R.v0[1] == T.v0y && R.v0[2] == T.v0z && ea[0] == T.e1x && ea[1] == T.e1y && ea[2] == T.e1z &&
+                                  eb[0] == T.e2x && eb[1] == T.e2y && eb[2] == T.e2z, "%s: arena record at %u half %d is not DevTri %d bit for bit", name, ru, half, sl);
+                        double tl[3], th[3];
+                        tri_box(T, tl, th);
+                        const uint32_t bw[3] = {W.bx[k], W.by[k], W.bz[k]};
+                        for (int a = 0; a < 3; a++)
+                            CHECK(val((uint16_t)(bw[a] & 0xffffu), a) <= tl[a] && val((uint16_t)(bw[a] >> 16), a) >= th[a], "%s: arena child box does not contain triangle %d", name, sl);
+                    }
+                }
+            }
+        };
+        awalk(0, 0, 0);
+        for (size_t k = 0; k < n; k++) CHECK(slot2[k] == 1, "%s: DevTri slot %zu in %d arena records", name, k, slot2[k]);
+        for (size_t u = 0; u < A.size(); u++) CHECK(unit_used[u] <= 1, "%s: arena unit %zu reached %d times", name, u, unit_used[u]);
+        CHECK(n_nodes == ia.wide_nodes && n_recs == ia.leaf_records, "%s: arena counts", name);
+        CHECK(max_entries <= ia.wide_stack, "%s: arena stack bound %llu < %llu", name, (unsigned long long)ia.wide_stack, (unsigned long long)max_entries);
+        CHECK(ia.wide_stack <= info.wide_stack || info.wide_stack == 0, "%s: the per-node bound %llu exceeds the per-child bound %llu", name,
+              (unsigned long long)ia.wide_stack, (unsigned long long)info.wide_stack);
+        std::printf("   arena: %zu units, %llu nodes, %llu records (%llu leaves split), stack %llu entries (per child: %llu)\n", A.size(),
+                    (unsigned long long)ia.wide_nodes, (unsigned long long)ia.leaf_records, (unsigned long long)ia.split_leaves,
+                    (unsigned long long)ia.wide_stack, (unsigned long long)info.wide_stack);
+    }
     // ids survive the reordering as a permutation
+
     std::vector<int> ids_after;
     for (auto &t : tris) ids_after.push_back(t.id);
     std::sort(ids_before.begin(), ids_before.end());

@@ -62,4 +62,18 @@ def test_bench_multi_rank_branch_rehearsal(shard):
     assert d["roofline"]["samples_per_launch"] == 800 * 600 * 1024 / 2            # each rank's launch covers half the frame
     assert d["roofline"]["kernel"] == "render_split_kernel" and c["waves_per_pixel"] == 1
     assert "rccl_probe" not in d and "cpu_baseline" not in d                      # N = 1 extras only
-    assert d["step_breakdown_ms"]["render"] > 0 and d["step_breakdown_ms"]["all_gather"] > 0
+    b = d["step_breakdown_ms"]
+    assert b["render"] > 0 and b["all_gather"] > 0
+    # every rank's own spans: a slow rank, a slow gather and a slow launch path can be told apart
+    assert [r["rank"] for r in b["per_rank"]] == [0, 1]
+    for r in b["per_rank"]:
+        assert r["render"] > 0 and r["all_gather"] > 0 and r["wall_ms_per_step"] >= r["render"]
+        assert abs(r["wall_ms_per_step"] - (r["render"] + r["all_gather"] + r["reassembly"] + r["launch_overhead_ms"])) < 0.01
+    for name in ("render", "all_gather", "reassembly", "launch_overhead_ms"):
+        sp = b["spread_over_ranks"][name]
+        assert sp["min"] <= sp["mean"] <= sp["max"]
+    assert b["render"] == b["spread_over_ranks"]["render"]["max"] and "launch_overhead_ms" in b
+    # each rank reports the phases it reaches on stderr (a hang is then "rank k stopped after ...")
+    for rk in (0, 1):
+        for what in ("process group up (gloo)", "ctx created", "warm-up done", "timed 2 steps", "done"):
+            assert any(f"rank {rk}/2" in l and what in l for l in p.stderr.splitlines()), (rk, what, p.stderr[-1500:])

@@ -74,3 +74,26 @@ def test_bench_self_launches_ranks_and_fails_loudly_without_a_gpu():
         assert p.returncode != 0
         assert p.stdout.strip() == ""                                  # no bench line without the GPUs
         assert p.stderr.count("needs a GPU") == 2 or "invalid device ordinal" in p.stderr or "out of range" in p.stderr
+        # ... and the launcher says how far every rank got (round 5: a failed or hung 8-GPU run must explain itself)
+        assert "last phase each rank reached" in p.stderr
+        for rk in (0, 1):
+            assert any(l.strip().startswith(f"rank {rk}:") and "imported torch + flux_amd" in l for l in p.stderr.splitlines()), p.stderr[-1500:]
+
+
+def test_bench_launch_is_bounded_and_says_where_it_stopped():
+    """A multi-rank bench that does not finish within FLUX_BENCH_LAUNCH_TIMEOUT_S is ended by its launcher -- the launcher's own
+    process group, by id, never a pattern -- with a non-zero exit and one line per rank naming the last phase it reached
+    (a first 8-GPU run must explain its own failure).  Here the limit (2 s) ends the ranks while they are
+    still importing torch."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, FLUX_BENCH_LAUNCH_TIMEOUT_S="2")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert p.returncode == 124, (p.returncode, p.stderr[-1000:])
+    assert p.stdout.strip() == ""
+    assert "exceeded 2.0 s" in p.stderr and "rank 0:" in p.stderr and "rank 1:" in p.stderr
