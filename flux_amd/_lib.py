@@ -125,6 +125,17 @@ def _load():
             f"{LIB_PATH} not found: build it with `python -m flux_amd.build` "
             "(the renderer has no CPU fallback)")
     lib = C.CDLL(LIB_PATH)
+    # the version FIRST: a stale library lacks newer symbols, and the loop below would die on the first of them with a bare
+    # AttributeError instead of saying what to do
+    try:
+        lib.flux_abi_version.restype = C.c_uint32
+        lib.flux_abi_version.argtypes = []
+        have = int(lib.flux_abi_version())
+    except AttributeError:
+        have = 1  # version 1 had no such symbol
+    if have != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} speaks ABI version {have}, this binding {ABI_VERSION}: rebuild it "
+                          "(python -m flux_amd.build --force)")
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
         fn.restype = res
@@ -133,9 +144,6 @@ def _load():
 
 
 lib = _load()
-if lib.flux_abi_version() != ABI_VERSION:
-    raise ImportError(f"{LIB_PATH} speaks ABI version {lib.flux_abi_version()}, this binding {ABI_VERSION}: rebuild it "
-                      "(python -m flux_amd.build --force)")
 
 
 def last_error():

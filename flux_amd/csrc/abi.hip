@@ -605,8 +605,17 @@ static bool holds_all_sets(const flux_ctx *c) { return c->sets.stride == 1 && c-
 // 69-71) then meets its zeros and infinities in an order no reordered product reproduces (a 240 000-scene soak: three
 // pixels' channels finite in FAST where the reference holds NaN).  Such a scene is rendered with the
 // STRICT arithmetic, whatever flux_ctx_set_math says: the reference's own operation order, identical in every soak scene.
+// ... unless STRICT cannot run the job at all: it keeps 32 B of recursion stack per level and lane in LDS (one wave per block
+// holds 31 levels beside nothing else), FAST keeps none.  A FAST job deeper than that, on such a scene, stays with FAST and its
+// long-form glossy weights (RenderParams::glossy_long; what every FAST render of such a scene was before round 4: the
+// reference's NaN pixels in all but the rarest orderings of an overflow and a zero) instead of being refused.
+static bool strict_fits_lds(const flux_ctx *ctx) {
+    const size_t stack = (size_t)ctx->D * 4 * 64 * sizeof(double);
+    const size_t bvh = (ctx->rp.n_tris > 0 && ctx->traversal != FLUX_TRAVERSE_BRUTE) ? (size_t)ctx->bvh.max_depth * 64 * sizeof(int) : 0;
+    return stack + bvh + 512 <= 64 * 1024;  // (the smallest block the planner can choose: one wave; plan_render_impl)
+}
 static int effective_math(const flux_ctx *ctx) {
-    return (ctx->math == FLUX_MATH_FAST && ctx->rp.glossy_long) ? FLUX_MATH_STRICT : ctx->math;
+    return (ctx->math == FLUX_MATH_FAST && ctx->rp.glossy_long && strict_fits_lds(ctx)) ? FLUX_MATH_STRICT : ctx->math;
 }
 
 // LDS one block of the kernel about to be launched needs: asked of the launch plan itself (render_body.inc plan_render_impl:
@@ -617,10 +626,12 @@ static int check_lds_budget(const flux_ctx *ctx, const flux::RenderParams &p, co
     const size_t dyn = flux::plan_render(p, ctx->variant, effective_math(ctx)).lds;
     const size_t fixed = 512;
     if (dyn + fixed > 64 * 1024)
-        return fail(FLUX_E_INVALID, "%s: %zu B of LDS per block (max_trace_depth %u%s, BVH depth %llu) exceed the 64 KiB limit; "
-                    "use FLUX_MATH_FAST or a smaller max_trace_depth", what, dyn + fixed, ctx->D,
-                    effective_math(ctx) == FLUX_MATH_STRICT ? " in the STRICT arithmetic (FLUX_MATH_STRICT, or a scene with a non-unit plane normal): 32 B of recursion stack per level and lane" : "",
-                    (unsigned long long)(p.bvh_stack > 0 ? ctx->bvh.max_depth : 0));
+        return fail(FLUX_E_INVALID, "%s: %zu B of LDS per block (max_trace_depth %u%s, BVH depth %llu) exceed the 64 KiB limit; use %s", what,
+                    dyn + fixed, ctx->D,
+                    effective_math(ctx) == FLUX_MATH_STRICT ? " in the STRICT arithmetic: 32 B of recursion stack per level and lane" : "",
+                    (unsigned long long)(p.bvh_stack > 0 ? ctx->bvh.max_depth : 0),
+                    // (a FAST context only gets here in FAST: the routing to STRICT is dropped where STRICT does not fit)
+                    ctx->math == FLUX_MATH_STRICT ? "FLUX_MATH_FAST or a smaller max_trace_depth" : "a smaller max_trace_depth");
     return FLUX_OK;
 }
 // flux_debug_shade: 64-thread blocks, STRICT recursion stack + per-lane BVH stack (render_body.inc launch_shade_rays_impl)

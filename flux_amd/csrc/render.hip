@@ -111,14 +111,19 @@ static_assert(!FLUX_BVH4_EARLY_REFILL || FLUX_BVH4_EARLY_AT >= FLUX_BVH_REFILL_A
 #define FLUX_BVH_LEAF_DEN 3       //     2:3 175.9, 1:2 176.4, 1:3 179.7, 3:2 178.8 ms at 1024 spp)
 #endif
 #ifndef FLUX_WAVES_PER_EU_FAST
-#define FLUX_WAVES_PER_EU_FAST 5
+#define FLUX_WAVES_PER_EU_FAST 5  // FAST render_refill_kernel without meshes: 94 VGPRs, nothing spilled
 #endif
+#ifndef FLUX_WAVES_PER_EU_FAST_WIDE
+#define FLUX_WAVES_PER_EU_FAST_WIDE 4  // FAST render_static_kernel (12 VGPRs spilled under the 5-wave cap) and the mesh instantiations of
+#endif                                 // render_refill_kernel (15 spilled): 4 waves/SIMD, nothing spilled (round 5; they shared the cap tuned
+                                       // for the refill kernel in round 1)
 
 
 // The loop itself lives in render_body.inc and is compiled twice (see its header): the STRICT
 // arithmetic (reference operation order, no contraction) and the FAST arithmetic (FMA + flux_math.h).
 #define FLUX_FAST 0
 #define FLUX_WPE FLUX_WAVES_PER_EU
+#define FLUX_WPE_WIDE FLUX_WAVES_PER_EU
 #pragma clang fp contract(off)
 namespace flux {
 namespace strict {
@@ -127,9 +132,11 @@ namespace strict {
 }  // namespace flux
 #undef FLUX_FAST
 #undef FLUX_WPE
+#undef FLUX_WPE_WIDE
 
 #define FLUX_FAST 1
 #define FLUX_WPE FLUX_WAVES_PER_EU_FAST
+#define FLUX_WPE_WIDE FLUX_WAVES_PER_EU_FAST_WIDE
 #pragma clang fp contract(fast)
 namespace flux {
 namespace fast {
@@ -159,6 +166,7 @@ hipError_t generate_gloss_table(const double2 *pix, size_t count, double *gloss,
 }  // namespace flux
 #undef FLUX_FAST
 #undef FLUX_WPE
+#undef FLUX_WPE_WIDE
 #pragma clang fp contract(off)
 
 namespace flux {

@@ -35,6 +35,36 @@ class Renderer:
         _lib.check(_lib.lib.flux_ctx_create_sets(C.byref(self._desc.desc), C.byref(cfg), C.c_uint64(self.seed),
                                                  self.device, self.set_share[0], self.set_share[1], C.byref(h)))
         self._h = h
+        self._warn_if_routed()
+
+    def _warn_if_routed(self):
+        """FLUX_MATH_FAST is defined for unit surface normals; a scene with a NON-unit plane normal is rendered with the STRICT
+        arithmetic (about 4.8 x slower, no traversal kernels for meshes) whatever set_math says -- reported once per renderer
+        instead of being found by polling launch_plan()["math"]."""
+        if getattr(self, "_routed_warned", False):
+            return
+        if self.requested_math == _lib.MATH_FAST and self.effective_math() == _lib.MATH_STRICT:
+            self._routed_warned = True
+            import warnings
+            warnings.warn("flux_amd: this scene has a plane stored with a non-unit normal, so FLUX_MATH_FAST renders it with the STRICT "
+                          "arithmetic (the reference's operation order, incl. its NaN pixels): several times slower. Normalise the "
+                          "plane normals to get the FAST kernels.", RuntimeWarning, stacklevel=3)
+
+    requested_math = _lib.MATH_FAST
+
+    def effective_math(self) -> int:
+        """The arithmetic a render really runs with (flux_ctx_launch_plan word 5)."""
+        return self.launch_plan(num_rows=1)["math"]
+
+    def __repr__(self):
+        names = {_lib.MATH_FAST: "FAST", _lib.MATH_STRICT: "STRICT"}
+        try:
+            eff = self.effective_math()
+            math = names[self.requested_math] + ("" if eff == self.requested_math else f" -> {names[eff]} (non-unit plane normal)")
+        except Exception:
+            math = "closed"
+        return (f"Renderer({self.scene_data.scene_name!r}, {self.width}x{self.height}, sample_root {self.config.sample_root}, "
+                f"depth {self.config.max_trace_depth}, seed {self.seed}, device {self.device}, math {math})")
 
     # -- lifetime ------------------------------------------------------------
     def close(self):
@@ -115,6 +145,8 @@ class Renderer:
     def set_math(self, mode: int):
         """MATH_FAST (default) or MATH_STRICT (reference operation order); include/flux_abi.h."""
         _lib.check(_lib.lib.flux_ctx_set_math(self._handle(), mode))
+        self.requested_math = int(mode)
+        self._warn_if_routed()
 
     def last_kernel_ms(self) -> float:
         return float(_lib.lib.flux_ctx_last_kernel_ms(self._handle()))

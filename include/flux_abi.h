@@ -207,7 +207,13 @@ int flux_ctx_set_kernel(flux_ctx *ctx, int variant);
  *       NON-unit normal makes reflected directions non-unit, lobes under- / overflow and the reference's recursion meet
  *       zeros and infinities in its own order (NaN pixels): a scene that has one is rendered with the STRICT arithmetic
  *       whatever this setting says, so the reference's NaN pixels appear exactly (flux_ctx_launch_plan reports the
- *       arithmetic in use);
+ *       arithmetic in use).  WHAT THAT COSTS: STRICT renders demo2 at 16384 spp in 1.08 s where FAST
+ *       takes 0.23 s, and a mesh scene also loses both traversal kernels -- so `normal: [0, 2, 0]`, or a normal typed to four
+ *       digits ([0.7071, 0, 0.7071]: |n|^2 = 0.99997), is a 4.8 x slower scene than the same plane normalised to double
+ *       precision.  The test is |n.n - 1| > 4 eps and is not looser on purpose: FAST takes every direction as a unit vector,
+ *       and a normal that is off by 3e-5 bends every reflection off it by as much, which is above the parity tolerance.
+ *       One exception: where the STRICT arithmetic cannot run the job at all (its LDS recursion stack holds 31 levels of
+ *       max_trace_depth), such a scene stays with FAST and the reference's long-form glossy weights, as before round 4;
  *   FLUX_MATH_STRICT: the reference's operation order, no contraction, IEEE division/sqrt, OCML
  *       pow/sincos, BoundingBox::hit before every sphere, (f,s) stack folded deepest bounce first. */
 #define FLUX_MATH_FAST 0
@@ -239,8 +245,9 @@ int flux_ctx_stats(flux_ctx *ctx, uint64_t out[FLUX_NUM_STATS], int reset);
 
 /* BVH introspection (extension): out[0] nodes of the binary tree, [1] triangles, [2] its max depth, [3] max leaf size,
  * [4] its node bytes, [5] triangle-record bytes, [6] build microseconds; the 4-wide tree the FAST traversal kernel walks:
- * [7] nodes, [8] leaf records, [9] of them holding two triangles (the halves of a quad), [10] most stack entries at once,
- * [11] node bytes, [12] leaf-record bytes, [13] 1 if a full-frame render with the context's current settings walks the
+ * [7] nodes, [8] leaf records, [9] of them holding two triangles (the halves of a quad), [10] most stack entries at once
+ * (one 32-bit entry per node with two children or more on a path: the 4-wide tree's depth), [11] node bytes, [12] leaf-record
+ * bytes, [13] 1 if a full-frame render with the context's current settings walks the
  * 4-wide tree (flux_ctx_launch_plan's kernel == FLUX_PLAN_BVH4); [14..15] reserved (0).
  * Writes min(out_words, FLUX_BVH_INFO_WORDS) words: a caller states the capacity of its buffer. */
 #define FLUX_BVH_INFO_WORDS 16

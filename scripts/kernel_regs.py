@@ -16,7 +16,7 @@ spec.loader.exec_module(b)
 
 INST = {"bvh4": "render_bvh4_kernel<false>", "bvh": "render_bvh_kernel<false>", "split": "render_split_kernel<false>",
         "refill": "render_refill_kernel<false, false>", "static": "render_static_kernel<false, false>",
-        "bvh4s": "render_bvh4_kernel<true>"}
+        "bvh4s": "render_bvh4_kernel<true>", "refill_tris": "render_refill_kernel<false, true>", "static_tris": "render_static_kernel<false, true>"}
 args = sys.argv[1:]
 asm_out = None
 if "--asm" in args:
@@ -34,6 +34,7 @@ head = render[:render.index("// The loop itself lives in render_body.inc")]  # i
 src = head + f'''
 #define FLUX_FAST 1
 #define FLUX_WPE FLUX_WAVES_PER_EU_FAST
+#define FLUX_WPE_WIDE FLUX_WAVES_PER_EU_FAST_WIDE
 #define FLUX_EXP_NO_LAUNCH 1
 #pragma clang fp contract(fast)
 namespace flux {{

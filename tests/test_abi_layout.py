@@ -88,3 +88,68 @@ def test_ctypes_mirror_matches_header(header_layout):
     for s, cls in mirror.items():
         assert C.sizeof(cls) == header_layout[s]["size"], s
         assert [(n, getattr(cls, n).offset) for n, _ in cls._fields_] == header_layout[s]["fields"], s
+
+
+# ---- functions: INTEGRATION.md's Rust `extern "C"` block against the header's prototypes ---------------
+C_TO_RUST = {
+    "int": "c_int", "double": "f64", "uint64_t": "u64", "int64_t": "i64", "uint32_t": "u32", "void": "()",
+    "const char *": "*const c_char", "const double *": "*const f64", "double *": "*mut f64", "uint64_t *": "*mut u64",
+    "int64_t *": "*mut i64", "int32_t *": "*mut i32", "const uint8_t *": "*const u8", "void *": "*mut c_void",
+    "flux_ctx *": "*mut FluxCtx", "flux_ctx **": "*mut *mut FluxCtx", "const flux_scene_desc *": "*const FluxSceneDesc",
+    "const flux_job_cfg *": "*const FluxJobCfg", "flux_work_unit *": "*mut FluxWorkUnit",
+}
+
+
+def _c_prototypes():
+    """name -> (return type, [argument types]) of every function include/flux_abi.h declares (array parameters decay)."""
+    hdr = open(os.path.join(ROOT, "include", "flux_abi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"^([a-z_0-9]+(?:\s+[a-z_0-9]+)*\s*\**)\s*(flux_[a-z_0-9]+)\(([^;{]*?)\);", hdr, flags=re.M | re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        norm = lambda t: re.sub(r"\s*\*", " *", " ".join(t.split())).replace("* *", "**").strip()
+        types = []
+        if args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                arr = re.search(r"\[[A-Z_0-9a-z]*\]$", a)
+                a = re.sub(r"\[[A-Z_0-9a-z]*\]$", "", a)
+                mm = re.match(r"^(.*?)([a-z_0-9]+)$", a)
+                t = norm(mm.group(1))
+                if arr:
+                    t = norm(t + " *")
+                types.append(t)
+        protos[name] = (norm(ret), types)
+    return protos
+
+
+def _rust_prototypes():
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r'extern "C" \{(.*?)\n\}', md, flags=re.S)
+    assert len(blocks) == 1, "ONE extern block binds the whole header"
+    body = re.sub(r"//[^\n]*", "", blocks[0])
+    protos = {}
+    for m in re.finditer(r"pub fn (flux_[a-z_0-9]+)\((.*?)\)\s*(?:->\s*([^;]+?))?\s*;", body, flags=re.S):
+        name, args, ret = m.group(1), " ".join(m.group(2).split()), (m.group(3) or "()").strip()
+        types = [a.split(":", 1)[1].strip() for a in args.split(",") if a.strip()]
+        protos[name] = (ret, types)
+    return protos
+
+
+def test_integration_md_rust_block_binds_every_function():
+    c, rust = _c_prototypes(), _rust_prototypes()
+    assert len(c) >= 26, sorted(c)                    # the parser saw the whole header
+    assert set(rust) == set(c), (sorted(set(c) - set(rust)), sorted(set(rust) - set(c)))
+    for name, (ret, args) in c.items():
+        r_ret, r_args = rust[name]
+        assert len(r_args) == len(args), (name, args, r_args)
+        assert r_ret == C_TO_RUST[ret], (name, ret, r_ret)
+        for k, (ca, ra) in enumerate(zip(args, r_args)):
+            assert ra == C_TO_RUST[ca], (name, k, ca, ra)
+
+
+def test_ctypes_binding_names_every_function():
+    """flux_amd/_lib.py binds the same set (its SYMBOLS table is what tests/test_abi_symbols.py loads)."""
+    src = open(os.path.join(ROOT, "flux_amd", "_lib.py")).read()
+    for name in _c_prototypes():
+        assert re.search(r"\b" + name + r"\b", src), name

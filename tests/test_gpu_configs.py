@@ -2,7 +2,8 @@
 them in seconds), plus the pieces that only exist for them:
 
  * config 2  scenes/demo1.yml 800x600 @256 spp (sample_root 16): determinism, kernel variants equal up to summation
-             order, finite / [0,1], path-statistics identities and their equality across kernels;
+             order, finite / [0,1], path-statistics identities and their equality across kernels; rows 0, 1, 299, 300 of the
+             full-size frame against the oracle (1e-4 / 1e-9 at the 99.9th percentile, equal statistics), FAST and STRICT;
  * config 3  scenes/demo2.yml 800x600 @1024 spp (sample_root 32), the FULL frame: determinism, split == refill == static up to
              summation order with identical path statistics, finite / [0,1], rows 0-1 and 298-301 against the oracle;
  * config 4  the per-rank contexts of the set-sharded frame (flux_ctx_create_sets): same tables, same pixels as the
@@ -23,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 # ------------------------------------------------------------------------------------------------ config 2
 @pytest.mark.parametrize("math", ["fast", "strict"])
-def test_config2_full_size_properties(flux, demo1, math):
+def test_config2_full_size_properties(flux, oracle_mod, demo1, math):
     mode = flux.MATH_FAST if math == "fast" else flux.MATH_STRICT
     with flux.Renderer(demo1, flux.JobConfiguration(16, 5, 50), seed=1) as r:
         r.set_math(mode)
@@ -55,6 +56,24 @@ def test_config2_full_size_properties(flux, demo1, math):
         r.set_math(mode)
         for u in flux.work_units(600, 50)[::5]:
             assert np.array_equal(r.render_rows(u.row_start, u.row_end), a[u.row_start:u.row_end + 1])
+        # ... and four rows of the FULL-SIZE frame meet the oracle (trace.rs:71-87: 4 x 800 x 256 = 0.8 M samples on the CPU): the
+        # horizon rows 0-1 and rows 299-300 through the spheres, at the north-star tolerance, with equal path statistics
+        rows = np.array([0, 1, 299, 300], dtype=np.int32)
+        o = oracle_mod.Oracle(demo1, flux.JobConfiguration(16, 5, 50), seed=1)
+        want = o.render_row_list(rows)
+        assert max_abs_diff(a[rows], want) < 1e-4
+        assert np.percentile(np.abs(a[rows] - want), 99.9) < 1e-9
+        r.enable_stats(True)
+        for row in (0, 300):
+            r.stats(reset=True)
+            r.render_rows(row, row)
+            got = r.stats(reset=True)
+            o.stats(reset=True)
+            o.render_row_list(np.array([row], dtype=np.int32))
+            ost = o.stats(reset=True)
+            for k in ("samples", "segments", "matte_bounces", "glossy_bounces", "specular_bounces", "emissive_hits", "misses", "depth_exhausted"):
+                assert got[k] == ost[k], (row, k, got[k], ost[k])
+        o.close()
 
 
 # ------------------------------------------------------------------------------------------------ config 3

@@ -480,6 +480,47 @@ def test_fast_means_strict_where_a_plane_normal_is_not_unit(flux, oracle_mod, de
     assert max_abs_diff(frames[("unit", "fast")], frames[("unit", "strict")]) < TOL_TIGHT
 
 
+def test_a_job_too_deep_for_strict_stays_fast_on_a_non_unit_plane(flux, oracle_mod, demo2):
+    """STRICT keeps 32 B of recursion stack per level and lane in LDS -- 31 levels at most.  A FAST job deeper
+    than that on a scene with a non-unit plane normal used to be routed to STRICT and then REFUSED (it rendered before round 4);
+    now the routing is dropped where STRICT cannot run: the launch plan says FAST, the frame comes from FAST's long-form glossy
+    weights (RenderParams::glossy_long) and meets the oracle; the same job in explicit STRICT is refused with a message that names
+    FLUX_MATH_FAST, and the Renderer warns once where the routing does apply."""
+    import copy
+    import warnings
+    sd = copy.deepcopy(small_scene(demo2, 32, 24))
+    plane = next(s for s in sd.shapes if isinstance(s, flux.PlaneData))
+    plane.normal = tuple(1.7 * x for x in plane.normal)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with flux.Renderer(sd, flux.JobConfiguration(8, 5, 50), seed=9) as r:      # depth 5: STRICT fits, the routing applies
+            assert r.launch_plan()["math"] == flux.MATH_STRICT and "FAST -> STRICT" in repr(r)
+        assert sum("non-unit normal" in str(x.message) for x in w) == 1
+    cfg = flux.JobConfiguration(16, 40, 50)
+    o = oracle_mod.Oracle(sd, cfg, seed=9)
+    o.stats(reset=True)
+    want = o.render_frame(threads=8)
+    ost = o.stats()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with flux.Renderer(sd, cfg, seed=9) as r:
+            assert r.launch_plan()["math"] == flux.MATH_FAST and "->" not in repr(r)
+            assert r.launch_plan()["kernel"] == flux._lib.PLAN_SPLIT          # 256 spp: the default kernel, long-form glossy weights
+            r.enable_stats(True)
+            for variant in (flux.KERNEL_DEFAULT, flux.KERNEL_REFILL, flux.KERNEL_STATIC):
+                r.set_kernel(variant)
+                r.stats(reset=True)
+                got = r.render_frame()
+                st = r.stats(reset=True)
+                assert {k: st[k] for k in ost} == ost, variant
+                finite = np.isfinite(want) & np.isfinite(got)
+                assert finite.mean() > 0.99 and max_abs_diff(got[finite], want[finite]) < TOL_IMAGE, variant
+            r.set_math(flux.MATH_STRICT)
+            with pytest.raises(flux.FluxError, match="FLUX_MATH_FAST or a smaller max_trace_depth"):
+                r.render_frame()
+        assert not any("non-unit normal" in str(x.message) for x in w)
+
+
 def test_strict_fits_its_waves_per_pixel_to_the_recursion_stack(flux, demo2):
     """STRICT keeps 32 B of (f, s) recursion stack per level and lane in LDS.  At 16384 spp four waves share a pixel (K = 4,
     256 lanes): seven levels fit the 64 KiB a block may have.  A deeper job used to be refused; now K falls to what fits (a
