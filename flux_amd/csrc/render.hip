@@ -110,6 +110,12 @@ static_assert(!FLUX_BVH4_EARLY_REFILL || FLUX_BVH4_EARLY_AT >= FLUX_BVH_REFILL_A
 #define FLUX_BVH_LEAF_NUM 2       // ... i.e. when n_leaf * NUM > n_inner * DEN (re-swept after the node step got cheaper: 1:1 178.4,
 #define FLUX_BVH_LEAF_DEN 3       //     2:3 175.9, 1:2 176.4, 1:3 179.7, 3:2 178.8 ms at 1024 spp)
 #endif
+#ifndef FLUX_STRICT_BOX_HWMINMAX
+#define FLUX_STRICT_BOX_HWMINMAX 1 // STRICT BoundingBox::hit: the reference's min / max forms through v_min_f64 / v_max_f64 + one unordered compare
+#endif                             //   of the z slab (the same verdict bit for bit, render_body.inc scene_hit)
+#ifndef FLUX_STRICT_SCAN_UNROLL
+#define FLUX_STRICT_SCAN_UNROLL 4  // STRICT shape scan: records fetched this many at a time (scalar loads issued together); demo2 @16384 spp 1035 -> 1026 ms
+#endif
 #ifndef FLUX_WAVES_PER_EU_FAST
 #define FLUX_WAVES_PER_EU_FAST 5  // FAST render_refill_kernel without meshes: 94 VGPRs, nothing spilled
 #endif

@@ -21,6 +21,8 @@ for n in roots:
     r = flux_amd.Renderer(sd, flux_amd.JobConfiguration(n, 5, 50), seed=1)
     t_create = time.time() - t
     print(f"{scene} n={n} spp={n*n}: ctx_create {t_create*1e3:.1f} ms, HBM {r.device_bytes()/1e6:.1f} MB, bvh {r.bvh_info()}", flush=True)
+    if os.environ.get("FLUX_MATH") == "strict":   # (scripts/valu_classes.sh on the STRICT kernels)
+        r.set_math(flux_amd.MATH_STRICT)
     for v in variants:
         r.set_kernel(v)
         for rep in range(2):
