@@ -338,7 +338,18 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         }
     }
     const size_t fs_s32_bytes = (fsph32.size() + 4) * sizeof(flux::DevScanSphere32);  // +4 pairs: the filter loads whole groups of 8 spheres
-    std::vector<unsigned char> fscene(fs_sph_bytes + fs_pln_bytes + fs_rec_bytes + fs_s32_bytes, 0);
+    // STRICT's sphere records in SCAN order (round 5: its scan takes its candidates from the same f32 filter, whose bit k is scan
+    // sphere k): the DevShape as it is, with the YAML index -- the tie rule's key -- in pad0
+    std::vector<flux::DevShape> sshapes;
+    for (size_t i = 0; i < ns; i++)
+        if (shapes[i].kind == flux::kShapeSphere) {
+            sshapes.push_back(shapes[i]);
+            sshapes.back().pad0 = (int32_t)i;
+        }
+    const size_t fs_ss_off = (fs_sph_bytes + fs_pln_bytes + fs_rec_bytes + fs_s32_bytes + 127) & ~(size_t)127;
+    const size_t fs_ss_bytes = (sshapes.size() + 1) * sizeof(flux::DevShape);
+    std::vector<unsigned char> fscene(fs_ss_off + fs_ss_bytes, 0);
+    if (!sshapes.empty()) std::memcpy(fscene.data() + fs_ss_off, sshapes.data(), sshapes.size() * sizeof(flux::DevShape));
     if (!fsph32.empty())
         std::memcpy(fscene.data() + fs_sph_bytes + fs_pln_bytes + fs_rec_bytes, fsph32.data(), fsph32.size() * sizeof(flux::DevScanSphere32));
     if (!fsph.empty()) std::memcpy(fscene.data(), fsph.data(), fsph.size() * sizeof(flux::DevScanSphere));
@@ -558,6 +569,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.fsph32 = (FLUX_FILTER32 && filter32_ok)
                     ? reinterpret_cast<const flux::DevScanSphere32 *>(c->d_fscene + fs_sph_bytes + fs_pln_bytes + fs_rec_bytes)
                     : nullptr;
+    rp.sshapes = reinterpret_cast<const flux::DevShape *>(c->d_fscene + fs_ss_off);
     rp.bvh_mag = c->bvh.mag;
     rp.set_first = 0;
     rp.set_stride = 1;

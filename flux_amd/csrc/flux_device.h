@@ -208,6 +208,7 @@ struct RenderParams {
     const DevScanPlane *fpln;
     const DevHitRec *frec;  // [n_sph + n_pln]
     const DevScanSphere32 *fsph32;  // [n_sph] f32 candidate-filter records, or nullptr (a coordinate beyond f32's safe range)
+    const DevShape *sshapes;        // [n_sph] the spheres' STRICT records in scan order (pad0 = YAML index): STRICT's candidates
     int32_t n_sph, n_pln;
     double bvh_mag;  // largest |coordinate| of any mesh vertex (padding scale of the f32 slab test)
     // work, second axis: sample sets set_first + m*set_stride, m < set_count (default: all S sets).  When

@@ -113,6 +113,9 @@ static_assert(!FLUX_BVH4_EARLY_REFILL || FLUX_BVH4_EARLY_AT >= FLUX_BVH_REFILL_A
 #ifndef FLUX_STRICT_BOX_HWMINMAX
 #define FLUX_STRICT_BOX_HWMINMAX 1 // STRICT BoundingBox::hit: the reference's min / max forms through v_min_f64 / v_max_f64 + one unordered compare
 #endif                             //   of the z slab (the same verdict bit for bit, render_body.inc scene_hit)
+#ifndef FLUX_STRICT_FILTER
+#define FLUX_STRICT_FILTER 1       // STRICT Scene::hit: BoundingBox::hit + Sphere::hit only for the spheres FAST's conservative f32 filter passes
+#endif                             //   (a rejected sphere's quadratic says miss whatever its box says): the same frames bit for bit
 #ifndef FLUX_STRICT_SCAN_UNROLL
 #define FLUX_STRICT_SCAN_UNROLL 4  // STRICT shape scan: records fetched this many at a time (scalar loads issued together); demo2 @16384 spp 1035 -> 1026 ms
 #endif
