@@ -28,6 +28,15 @@ PUBLISHED_MSAMPLES_S = 7864.32 / 1479.900397
 # lane-operations one ray segment of demo2 needs at the least (12 sphere tests x 11 + 1.5 exact
 # candidates x 30 + plane 15 + shading 50) -- the yardstick `useful_valu_frac` holds the issued lane slots against
 USEFUL_LANE_OPS_PER_SEGMENT = 242.0
+# Mean issue cost of a kernel's VALU instructions in shader cycles, weighted by its DYNAMIC instruction classes (hardware class
+# counters, profiles/r04_experiments/valu_classes_r04.log) with the per-class costs measured in round 5
+# (scripts/micro/valu_issue.hip, profiles/r05_valu_issue.json: f64 / packed f32 / three-operand integer / e64 selects 4.1,
+# compares and conversions 4.7, plain f32 / integer / register moves / e32 selects 2.4, f64 transcendental seeds 16.1).  Until
+# round 4 every instruction was priced at 4.  Split kernel: 422 f64 x 4.13 + 11.5 x 16.1 + 65 packed x 4.13 + 14 f32 x 2.45 +
+# 15.5 cvt x 4.67 + 106 int32 x 3.3 + 402 unclassified (170 moves x 2.45, 100 compares x 4.75, 90 selects x 3.3, 42 lane ops and
+# others x 4.5) = 4 040 cycles per 1 039 instructions.  The mesh kernel's node step is all 4-cycle classes.
+ISSUE_CYCLES_PER_INST = {"render_split_kernel": 3.89, "render_bvh4_kernel": 4.1}
+NOMINAL_CLOCK_HZ = 2.4e9  # the chip runs these kernels at ~2.15-2.3 GHz (power management; measured by the microbenchmark)
 
 
 # BASELINE.md section 5 configurations -> (scene, sample_root): 2 = demo1 @256 spp, 3 = demo2 @1024 spp, 4 = the headline
@@ -445,8 +454,10 @@ def main():
                                      "L1 / L2 / Infinity Cache, and no counter on gfx950 separates HBM from Infinity-Cache traffic "
                                      "(l2_miss_traffic_gbs is an upper bound on the HBM rate); no HBM fraction is claimed")
         valu_insts = prof["valu_insts_per_launch"] * scale if prof and prof.get("valu_insts_per_launch") else None
-        # FP64-VALU issue ceiling: 256 CU x 4 SIMD, one wave-instruction per 4 cycles at 2.4 GHz = 614.4 G/s
-        issue_peak = 256 * 4 * 2.4e9 / 4
+        # VALU issue ceiling: 256 CU x 4 SIMD wave-instructions per (mean cycles per instruction of THIS kernel's mix) at the
+        # nominal 2.4 GHz -- 614 G/s at 4 cycles each, 632 G/s for the split kernel's measured mix
+        issue_cycles = ISSUE_CYCLES_PER_INST.get(kernel_name, 4.1)
+        issue_peak = 256 * 4 * NOMINAL_CLOCK_HZ / issue_cycles
         out = {
             "metric": (f"Msamples/sec on {a.scene}.yml (fixed spp)" if not a.scene.startswith("hf:") else
                        f"Msamples/sec on the procedural {a.scene[3:]} height field in the demo2 set (fixed spp)"),
@@ -505,10 +516,15 @@ def main():
                          "kernel_ms": round(kernel_ms_max, 3), "samples_per_launch": samples_launch,
                          "bytes_per_sample": round(bytes_per_sample, 3),
                          "bytes_per_sample_as_laid_out": round(bytes_per_sample + 24.0 * gbar, 3),
-                         # what actually bounds the analytic kernels: FP64-rate VALU issue (every VALU instruction, packed
-                         # f32 included, takes 4 cycles of a SIMD) -- from the committed PMC profile of this scene
+                         # what actually bounds the analytic kernels: VALU issue (f64, packed f32, compares, e64 selects: 4+ cycles of
+                         # a SIMD each; plain 32-bit arithmetic and moves 2.4) -- instruction counts from the committed PMC profile
                          "fp64_issue_frac": (None if valu_insts is None else
                                              round(valu_insts / (kernel_ms_max * 1e-3) / issue_peak, 4)),
+                         "issue_cycles_per_inst": issue_cycles,
+                         "issue_note": "fp64_issue_frac = VALU instructions/s x mean cycles per instruction of this kernel's class mix "
+                                       "(profiles/r05_valu_issue.json) / (1024 SIMDs x the NOMINAL 2.4 GHz); the chip clocks these "
+                                       "kernels at ~2.2 GHz, so ~0.92 here is a saturated VALU.  valu_busy_frac (SQ_ACTIVE_INST_VALU x 4 "
+                                       "/ cycles) charges every plain instruction 4 cycles and overstates by the two-cycle share",
                          "valu_busy_frac": prof.get("valu_busy_frac") if prof else None,
                          "lanes_active_frac": prof.get("lanes_active_frac") if prof else None,
                          "useful_valu_frac": (None if valu_insts is None or bvh["triangles"] or a.scene != "demo2" else
