@@ -120,12 +120,24 @@ def check_scene(flux, oracle_mod, sd, n, D, seed, tag0):
 @pytest.mark.parametrize("chunk", range(int(os.environ.get("FLUX_FUZZ_CHUNKS", "8"))))   # a longer soak: FLUX_FUZZ_CHUNKS=80
 def test_random_scenes_against_the_oracle(flux, oracle_mod, demo1, chunk):
     rng = np.random.default_rng(1000 + chunk)
+    # FLUX_FUZZ_COLLECT=1 (the long soaks): a scene that differs does not end its chunk -- the remaining scenes are still
+    # checked and the chunk fails at its END with every differing scene listed, so a soak's count of differing scenes is exact
+    # (until round 4 a chunk stopped at its first difference and the count was a lower bound)
+    collect = os.environ.get("FLUX_FUZZ_COLLECT") == "1"
+    differing = []
     for case in range(40):
         sd = random_scene(flux, demo1, rng, unit_planes=case % 2 == 1)
         n = int(rng.choice([1, 2, 3, 8, 9]))
         D = int(rng.choice([1, 3, 5, 9]))
         seed = int(rng.integers(1, 1 << 30))
-        check_scene(flux, oracle_mod, sd, n, D, seed, f"chunk {chunk} case {case}")
+        if not collect:
+            check_scene(flux, oracle_mod, sd, n, D, seed, f"chunk {chunk} case {case}")
+            continue
+        try:
+            check_scene(flux, oracle_mod, sd, n, D, seed, f"chunk {chunk} case {case}")
+        except AssertionError as e:
+            differing.append(str(e).splitlines()[0][:200] + " || " + " ".join(l.strip() for l in str(e).splitlines()[1:8] if "!=" in l)[:300])
+    assert not differing, f"{len(differing)} DIFFERING SCENE(S) in chunk {chunk}: " + " ## ".join(differing)
 
 
 # The nine scenes in which FLUX_MATH_FAST differed from the reference in round 3's 240 000-scene soak of the old generator
