@@ -521,6 +521,41 @@ def test_a_job_too_deep_for_strict_stays_fast_on_a_non_unit_plane(flux, oracle_m
         assert not any("non-unit normal" in str(x.message) for x in w)
 
 
+def test_strict_filter_equals_the_full_scan(flux, demo1, demo2):
+    """Round 5: STRICT takes its sphere candidates from FAST's conservative f32 filter (a sphere the filter rejects is a miss
+    whatever BoundingBox::hit says, shapes.rs:173-214) and runs box + quadratic exactly as the reference has them for the rest.
+    The frames must be the SAME BITS as with the full scan.  The full scan is still in the library -- it serves scenes the f32
+    filter is not defined for (a coordinate beyond 1e15) -- so the same scene with one unreachable sphere at x = 1e16 appended
+    (last: nobody's YAML index moves) renders through it: frames and path statistics equal bit for bit, demo1, demo2 and fuzz
+    scenes with inverted spheres, coincident twins and non-unit planes, static and refill kernels.
+    (scripts/strict_filter_check.py does the same against a -DFLUX_STRICT_FILTER=0 build of the library.)"""
+    import copy
+    from test_gpu_fuzz import random_scene
+    scenes = [(small_scene(demo1, 96, 72), 8, 5, 1), (small_scene(demo2, 96, 72), 8, 5, 2)]
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        scenes.append((random_scene(flux, demo1, rng, unit_planes=case % 2 == 1), int(rng.choice([1, 3, 8])), int(rng.choice([1, 5, 9])),
+                       int(rng.integers(1, 1 << 30))))
+    for sd, n, D, seed in scenes:
+        far = copy.deepcopy(sd)
+        far.shapes = list(far.shapes) + [flux.SphereData((1.0e16, 0.0, 0.0), 1.0, flux.MatteData((0.5, 0.5, 0.5), (0, 0, 0), 1.0), False)]
+        cfg = flux.JobConfiguration(n, D, 50)
+        out = []
+        for scene in (sd, far):
+            with flux.Renderer(scene, cfg, seed=seed) as r:
+                r.set_math(flux.MATH_STRICT)
+                r.enable_stats(True)
+                for variant in (flux.KERNEL_STATIC, flux.KERNEL_REFILL):
+                    r.set_kernel(variant)
+                    r.stats(reset=True)
+                    frame = r.render_frame()
+                    out.append((frame, r.stats(reset=True)))
+        half = len(out) // 2
+        for (fa, sa), (fb, sb) in zip(out[:half], out[half:]):
+            assert np.array_equal(fa, fb, equal_nan=True)
+            assert sa == sb
+
+
 def test_strict_fits_its_waves_per_pixel_to_the_recursion_stack(flux, demo2):
     """STRICT keeps 32 B of (f, s) recursion stack per level and lane in LDS.  At 16384 spp four waves share a pixel (K = 4,
     256 lanes): seven levels fit the 64 KiB a block may have.  A deeper job used to be refused; now K falls to what fits (a
