@@ -39,7 +39,7 @@ class Renderer:
 
     def _warn_if_routed(self):
         """FLUX_MATH_FAST is defined for unit surface normals; a scene with a NON-unit plane normal is rendered with the STRICT
-        arithmetic (about 4.8 x slower, no traversal kernels for meshes) whatever set_math says -- reported once per renderer
+        arithmetic (about 3.5 x slower, no traversal kernels for meshes) whatever set_math says -- reported once per renderer
         instead of being found by polling launch_plan()["math"]."""
         if getattr(self, "_routed_warned", False):
             return
