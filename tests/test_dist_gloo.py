@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: world_size 2 (and 3) over gloo.  Row sharding + one all_gather + reassembly
+"""The N>1 path on CPU: world_size 2, 3 and 8 (the SCALE run's world) over gloo.  Row sharding + one all_gather + reassembly
 (flux_amd/dist.py) must reproduce the single-process frame bit for bit.  The pixels come from the CPU
 oracle here (no GPU in this container); on GPUs the same FrameSharder is fed by the HIP library."""
 import os
@@ -63,7 +63,7 @@ def _worker(rank, world, port, height, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height", [(2, 16), (2, 15), (3, 16)])
+@pytest.mark.parametrize("world,height", [(2, 16), (2, 15), (3, 16), (8, 19)])   # 8 ranks: the SCALE run's world, ragged (19 rows)
 def test_sharded_frame_equals_single(tmp_path, world, height):
     _spawn(_worker, world, height, str(tmp_path))
     counts = []
@@ -117,7 +117,7 @@ def _set_worker(rank, world, port, width, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,width", [(2, 20), (2, 21), (3, 20)])
+@pytest.mark.parametrize("world,width", [(2, 20), (2, 21), (3, 20), (8, 20)])   # 8 ranks: 20 sets as 3,3,3,3,2,2,2,2
 def test_set_sharded_frame_equals_single(tmp_path, world, width):
     """SetSharder: ranks own sample sets (s % G == rank), one all_gather, reassembly through the row permutation;
     ragged set counts (21 sets over 2 ranks, 20 over 3) are padded."""
