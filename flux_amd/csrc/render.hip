@@ -113,6 +113,17 @@ static_assert(!FLUX_BVH4_EARLY_REFILL || FLUX_BVH4_EARLY_AT >= FLUX_BVH_REFILL_A
 #ifndef FLUX_STRICT_BOX_HWMINMAX
 #define FLUX_STRICT_BOX_HWMINMAX 1 // STRICT BoundingBox::hit: the reference's min / max forms through v_min_f64 / v_max_f64 + one unordered compare
 #endif                             //   of the z slab (the same verdict bit for bit, render_body.inc scene_hit)
+#ifndef FLUX_TRAV_RCP32
+#define FLUX_TRAV_RCP32 1          // BVH kernels: the slab test's 1 / d from v_rcp_f32 instead of three IEEE f64 divisions per ray segment
+#endif
+#ifndef FLUX_SPLIT_EARLY_SAMPLES
+#define FLUX_SPLIT_EARLY_SAMPLES 0 // render_split_kernel: phase A's pixel / lens samples requested before the queue pop (experiment, round 5)
+#endif
+#ifndef FLUX_SPLIT_LDS_SCENE
+#define FLUX_SPLIT_LDS_SCENE 1     // render_split_kernel: hit records + scan spheres copied into the block's LDS: the per-lane gathers in the middle of a
+                                   //   pass become LDS reads (round 5: the chip runs the kernel at 2.37 GHz and its VALU idles ~14 % of the cycles -- all
+                                   //   resident waves waiting on memory at once); demo2 @16384 spp 227.3 -> 222.6 ms
+#endif
 #ifndef FLUX_STRICT_FILTER
 #define FLUX_STRICT_FILTER 1       // STRICT Scene::hit: BoundingBox::hit + Sphere::hit only for the spheres FAST's conservative f32 filter passes
 #endif                             //   (a rejected sphere's quadratic says miss whatever its box says): the same frames bit for bit
