@@ -36,7 +36,7 @@ USEFUL_LANE_OPS_PER_SEGMENT = 242.0
 # 15.5 cvt x 4.67 + 106 int32 x 3.3 + 402 unclassified (170 moves x 2.45, 100 compares x 4.75, 90 selects x 3.3, 42 lane ops and
 # others x 4.5) = 4 040 cycles per 1 039 instructions.  The mesh kernel's node step is all 4-cycle classes.
 ISSUE_CYCLES_PER_INST = {"render_split_kernel": 3.89, "render_bvh4_kernel": 4.1}
-NOMINAL_CLOCK_HZ = 2.4e9  # the chip runs these kernels at ~2.15-2.3 GHz (power management; measured by the microbenchmark)
+NOMINAL_CLOCK_HZ = 2.4e9  # measured for the render kernels: 2.38 GHz (scripts/kernel_clock.sh); the microbenchmark's pure fma streams: 2.16
 
 
 # BASELINE.md section 5 configurations -> (scene, sample_root): 2 = demo1 @256 spp, 3 = demo2 @1024 spp, 4 = the headline
@@ -522,8 +522,8 @@ def main():
                                              round(valu_insts / (kernel_ms_max * 1e-3) / issue_peak, 4)),
                          "issue_cycles_per_inst": issue_cycles,
                          "issue_note": "fp64_issue_frac = VALU instructions/s x mean cycles per instruction of this kernel's class mix "
-                                       "(profiles/r05_valu_issue.json) / (1024 SIMDs x the NOMINAL 2.4 GHz); the chip clocks these "
-                                       "kernels at ~2.2 GHz, so ~0.92 here is a saturated VALU.  valu_busy_frac (SQ_ACTIVE_INST_VALU x 4 "
+                                       "(profiles/r05_valu_issue.json) / (1024 SIMDs x 2.4 GHz; the render kernels run at 2.38 GHz, "
+                                       "scripts/kernel_clock.sh): the fraction of cycles in which the VALU issues.  valu_busy_frac (SQ_ACTIVE_INST_VALU x 4 "
                                        "/ cycles) charges every plain instruction 4 cycles and overstates by the two-cycle share",
                          "valu_busy_frac": prof.get("valu_busy_frac") if prof else None,
                          "lanes_active_frac": prof.get("lanes_active_frac") if prof else None,
