@@ -113,6 +113,9 @@ static_assert(!FLUX_BVH4_EARLY_REFILL || FLUX_BVH4_EARLY_AT >= FLUX_BVH_REFILL_A
 #ifndef FLUX_STRICT_BOX_HWMINMAX
 #define FLUX_STRICT_BOX_HWMINMAX 1 // STRICT BoundingBox::hit: the reference's min / max forms through v_min_f64 / v_max_f64 + one unordered compare
 #endif                             //   of the z slab (the same verdict bit for bit, render_body.inc scene_hit)
+#ifndef FLUX_TRI_FDIV
+#define FLUX_TRI_FDIV 0            // FAST triangle test: 1 / det by fastmath::fdiv (<= 2 ulp) instead of the IEEE division: measured SLOWER (548.3 against 542.3 ms), off
+#endif
 #ifndef FLUX_TRAV_RCP32
 #define FLUX_TRAV_RCP32 1          // BVH kernels: the slab test's 1 / d from v_rcp_f32 instead of three IEEE f64 divisions per ray segment
 #endif
