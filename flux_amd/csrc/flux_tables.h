@@ -34,6 +34,7 @@ struct LaunchPlan {
     uint64_t blocks;
     size_t lds;  // dynamic LDS per block (the refill / split kernels add 96 B of static LDS)
     unsigned waves_per_pixel;  // K: waves that share one pixel's samples (1 in the static and BVH kernels)
+    int lds_scene;             // kernel 4: 1 = the instantiation that keeps the analytic set's records and the materials in LDS (`lds` includes them)
 };
 LaunchPlan plan_render(const RenderParams &p, int variant, int math);
 

@@ -113,6 +113,10 @@ static_assert(!FLUX_BVH4_EARLY_REFILL || FLUX_BVH4_EARLY_AT >= FLUX_BVH_REFILL_A
 #ifndef FLUX_STRICT_BOX_HWMINMAX
 #define FLUX_STRICT_BOX_HWMINMAX 1 // STRICT BoundingBox::hit: the reference's min / max forms through v_min_f64 / v_max_f64 + one unordered compare
 #endif                             //   of the z slab (the same verdict bit for bit, render_body.inc scene_hit)
+#ifndef FLUX_BVH4_LDS_SCENE
+#define FLUX_BVH4_LDS_SCENE 1      // render_bvh4_kernel: the analytic set's hit records, the materials and the scan spheres in the block's LDS while they are small
+                                   //   (stack + records <= 7 680 B, the 6 granules of 5 waves per SIMD: its own instantiation): the shading step's dependent gathers lose an L2 round trip; 1 M triangles 542.0 -> 530.9 ms
+#endif
 #ifndef FLUX_TRI_FDIV
 #define FLUX_TRI_FDIV 0            // FAST triangle test: 1 / det by fastmath::fdiv (<= 2 ulp) instead of the IEEE division: measured SLOWER (548.3 against 542.3 ms), off
 #endif
