@@ -14,7 +14,7 @@ ms = line["roofline"]["kernel_ms"]; name = line["roofline"]["kernel"]
 rows = {}
 for f in glob.glob(out + "/pmc/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if name + "<false>" in r["Kernel_Name"]:
+        if name + "<false" in r["Kernel_Name"]:
             rows.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
 v = [d for d in rows.values() if "GRBM_GUI_ACTIVE" in d]
 gui = sum(d["GRBM_GUI_ACTIVE"] for d in v) / len(v); busy = sum(d["SQ_BUSY_CYCLES"] for d in v) / len(v)
