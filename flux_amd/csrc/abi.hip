@@ -348,7 +348,17 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         }
     const size_t fs_ss_off = (fs_sph_bytes + fs_pln_bytes + fs_rec_bytes + fs_s32_bytes + 127) & ~(size_t)127;
     const size_t fs_ss_bytes = (sshapes.size() + 1) * sizeof(flux::DevShape);
-    std::vector<unsigned char> fscene(fs_ss_off + fs_ss_bytes, 0);
+    // The split kernel's per-pixel constants of the primary ray (trace.rs:56-57, 93-94) as two tables a wave reads with scalar loads in
+    // its ray-generation step: x - half_w for every column, (H - row) - half_h for every row -- the same two IEEE operations the
+    // kernels perform, done once here
+    const size_t fs_px_off = (fs_ss_off + fs_ss_bytes + 127) & ~(size_t)127;
+    std::vector<unsigned char> fscene(fs_px_off + ((size_t)c->W + c->H) * sizeof(double), 0);
+    {
+        double *pxc = reinterpret_cast<double *>(fscene.data() + fs_px_off);
+        const double half_w = (double)c->W * 0.5, half_h = (double)c->H * 0.5;
+        for (uint32_t x = 0; x < c->W; x++) pxc[x] = (double)(int32_t)x - half_w;
+        for (uint32_t y = 0; y < c->H; y++) pxc[c->W + y] = (double)((int32_t)c->H - (int32_t)y) - half_h;
+    }
     if (!sshapes.empty()) std::memcpy(fscene.data() + fs_ss_off, sshapes.data(), sshapes.size() * sizeof(flux::DevShape));
     if (!fsph32.empty())
         std::memcpy(fscene.data() + fs_sph_bytes + fs_pln_bytes + fs_rec_bytes, fsph32.data(), fsph32.size() * sizeof(flux::DevScanSphere32));
@@ -570,6 +580,10 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
                     ? reinterpret_cast<const flux::DevScanSphere32 *>(c->d_fscene + fs_sph_bytes + fs_pln_bytes + fs_rec_bytes)
                     : nullptr;
     rp.sshapes = reinterpret_cast<const flux::DevShape *>(c->d_fscene + fs_ss_off);
+    rp.pxc = reinterpret_cast<const double *>(c->d_fscene + fs_px_off);
+    rp.fwx = rp.focal * rp.Wx;  // trace.rs:96-98's focal_distance * w, one product per frame instead of per wave
+    rp.fwy = rp.focal * rp.Wy;
+    rp.fwz = rp.focal * rp.Wz;
     rp.bvh_mag = c->bvh.mag;
     rp.set_first = 0;
     rp.set_stride = 1;

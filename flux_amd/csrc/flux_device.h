@@ -235,6 +235,10 @@ struct RenderParams {
     // far?" on squared quantities and takes no square root (render_body.inc scan_shapes_fast<true>); env_radius = its radius
     int32_t env_short, pad_env;
     double env_radius;
+    // split kernel: the primary ray's per-frame and per-pixel constants, read with scalar loads in the ray-generation step instead of
+    // living in scalar registers across the pass loop: focal * (Wx, Wy, Wz); pxc[x] = x - half_w, pxc[img_w + row] = (img_h - row) - half_h
+    double fwx, fwy, fwz;
+    const double *pxc;
 };
 
 }  // namespace flux

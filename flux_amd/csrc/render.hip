@@ -70,8 +70,17 @@
 #ifndef FLUX_RELOAD_PARAMS
 #define FLUX_RELOAD_PARAMS 1      // render_refill_kernel, render_bvh_kernel: the same re-read of the kernel arguments per pass
 #endif
+#ifndef FLUX_SCALAR_VOTES
+#define FLUX_SCALAR_VOTES 1  // wave votes on boolean expressions written as scalar arithmetic on the lane masks of their compares (render_body.inc)
+#endif
+#ifndef FLUX_SCALAR_LIVE
+#define FLUX_SCALAR_LIVE 0  // render_split_kernel: the lane mask of `live` kept in scalar registers; bit 0: the pop, 1: "a lane is free", 2: "no lane is live" use it
+#endif
+#ifndef FLUX_SPLIT_OPAQUE_UNIFORMS
+#define FLUX_SPLIT_OPAQUE_UNIFORMS 3  // render_split_kernel: bit 0 = the sample set, bit 1 = the sphere masks opaque per pass (no loop-invariant scalar pairs derived from them)
+#endif
 #ifndef FLUX_SPLIT_PIXEL_CONSTS
-#define FLUX_SPLIT_PIXEL_CONSTS 1  // render_split_kernel: primary_ray's per-pixel constants kept in scalar registers
+#define FLUX_SPLIT_PIXEL_CONSTS 2  // render_split_kernel: primary_ray's per-pixel constants: 1 = kept in scalar registers, 2 = scalar loads from tables per pass
 #endif
 #ifndef FLUX_SPLIT_RELOAD_PARAMS
 #define FLUX_SPLIT_RELOAD_PARAMS 1 // render_split_kernel: kernel arguments re-read (scalar loads) in every pass instead of kept alive across the loop (38 SGPRs spilled to VGPR lanes)
