@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Compile ONE render kernel (no GPU needed) and print its registers, spills and occupancy -- the quick loop of a register
-diet: ~15 s instead of a full build.  usage: scripts/kernel_regs.py <kernel> [-Dflag ...] [--asm out.s] [--csrc dir]
+diet: ~15 s instead of a full build.  usage: scripts/kernel_regs.py <kernel> [--strict] [-Dflag ...] [--asm out.s] [--csrc dir]
    kernel: bvh4 | bvh | split | refill | static   (FAST arithmetic, the product instantiation: no statistics)"""
 import os
 import re
@@ -28,10 +28,13 @@ if "--csrc" in args:   # another checkout's flux_amd/csrc (A/B against an older 
     k = args.index("--csrc")
     csrc = os.path.abspath(args[k + 1])
     del args[k:k + 2]
+strict = "--strict" in args   # the STRICT arithmetic's instantiation of the same kernel (namespace flux::strict, no contraction)
+if strict:
+    args.remove("--strict")
 kernel, extra = args[0], args[1:]
 render = open(os.path.join(csrc, "render.hip")).read()
 head = render[:render.index("// The loop itself lives in render_body.inc")]  # includes + tunables
-src = head + f'''
+src = head + (f'''
 #define FLUX_FAST 1
 #define FLUX_WPE FLUX_WAVES_PER_EU_FAST
 #define FLUX_WPE_WIDE FLUX_WAVES_PER_EU_FAST_WIDE
@@ -43,7 +46,19 @@ namespace fast {{
 template __global__ void {INST[kernel]}(const RenderParams);
 }}
 }}
-'''
+''' if not strict else f'''
+#define FLUX_FAST 0
+#define FLUX_WPE FLUX_WAVES_PER_EU
+#define FLUX_WPE_WIDE FLUX_WAVES_PER_EU
+#define FLUX_EXP_NO_LAUNCH 1
+#pragma clang fp contract(off)
+namespace flux {{
+namespace strict {{
+#include "render_body.inc"
+template __global__ void {INST[kernel]}(const RenderParams);
+}}
+}}
+''')
 flags = [f for f in b.HIP_FLAGS if f not in ("-shared", "-fPIC")]
 with tempfile.TemporaryDirectory() as td:
     path = os.path.join(csrc, "_kernel_regs_tmp.hip")
