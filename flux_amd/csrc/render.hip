@@ -73,6 +73,9 @@
 #ifndef FLUX_SCALAR_VOTES
 #define FLUX_SCALAR_VOTES 1  // wave votes on boolean expressions written as scalar arithmetic on the lane masks of their compares (render_body.inc)
 #endif
+#ifndef FLUX_SPLIT_UNIFORM_SUB
+#define FLUX_SPLIT_UNIFORM_SUB 1  // render_split_kernel: the wave's index in its block read into a scalar register (cursor / queue count in SGPRs)
+#endif
 #ifndef FLUX_SCALAR_LIVE
 #define FLUX_SCALAR_LIVE 0  // render_split_kernel: the lane mask of `live` kept in scalar registers; bit 0: the pop, 1: "a lane is free", 2: "no lane is live" use it
 #endif
