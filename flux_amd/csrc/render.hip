@@ -139,9 +139,10 @@ static_assert(!FLUX_BVH4_EARLY_REFILL || FLUX_BVH4_EARLY_AT >= FLUX_BVH_REFILL_A
 #define FLUX_SPLIT_EARLY_SAMPLES 0 // render_split_kernel: phase A's pixel / lens samples requested before the queue pop (experiment, round 5)
 #endif
 #ifndef FLUX_SPLIT_LDS_SCENE
-#define FLUX_SPLIT_LDS_SCENE 1     // render_split_kernel: hit records + scan spheres copied into the block's LDS: the per-lane gathers in the middle of a
+#define FLUX_SPLIT_LDS_SCENE 2     // render_split_kernel: hit records + scan spheres copied into the block's LDS: the per-lane gathers in the middle of a
                                    //   pass become LDS reads (round 5: the chip runs the kernel at 2.37 GHz and its VALU idles ~14 % of the cycles -- all
-                                   //   resident waves waiting on memory at once); demo2 @16384 spp 227.3 -> 222.6 ms
+                                   //   resident waves waiting on memory at once); demo2 @16384 spp 227.3 -> 222.6 ms.  2 = the records FIRST in the
+                                   //   dynamic LDS (an address the compiler knows: no scalar register holds it), the queues behind them: 215.4 -> 214.9 ms
 #endif
 #ifndef FLUX_STRICT_FILTER
 #define FLUX_STRICT_FILTER 1       // STRICT Scene::hit: BoundingBox::hit + Sphere::hit only for the spheres FAST's conservative f32 filter passes
