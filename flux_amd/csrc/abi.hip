@@ -67,6 +67,7 @@ struct flux_ctx {
     double2 *d_pix = nullptr, *d_disc = nullptr;
     double *d_hemi = nullptr;
     double *d_gloss = nullptr;  // FAST glossy-lobe factors of pixel_sets
+    flux::DevSetRows *d_setrows = nullptr;  // per table slot: where the set's rows of the four tables start
     int32_t *d_rowperm = nullptr, *d_invperm = nullptr;
     unsigned long long *d_stats = nullptr;
     bool stats_on = false;
@@ -113,6 +114,7 @@ static void free_ctx(flux_ctx *c) {
     (void)hipFree(c->d_disc);
     (void)hipFree(c->d_hemi);
     (void)hipFree(c->d_gloss);
+    (void)hipFree(c->d_setrows);
     (void)hipFree(c->d_rowperm);
     (void)hipFree(c->d_invperm);
     (void)hipFree(c->d_stats);
@@ -506,6 +508,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     alloc((void **)&c->d_disc, pix_bytes);
     alloc((void **)&c->d_hemi, hemi_bytes);
     if (FLUX_GLOSS_TABLE) alloc((void **)&c->d_gloss, pix_bytes * 2);
+    alloc((void **)&c->d_setrows, own * sizeof(flux::DevSetRows));
     alloc((void **)&c->d_rowperm, perm_bytes);
     alloc((void **)&c->d_invperm, perm_bytes);
     alloc((void **)&c->d_stats, FLUX_NUM_STATS * sizeof(unsigned long long));
@@ -543,6 +546,18 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         e = flux::generate_gloss_table(c->d_pix, (size_t)c->sets.count * c->N, c->d_gloss, nullptr);
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     }
+    if (e == hipSuccess) {
+        // where each held set's rows of the sample tables start: one 32-B record per slot, so that a kernel forms a table address with one
+        // scalar load instead of a 64-bit multiply-add chain per table and pass (render_body.inc FLUX_SET_ROWS)
+        std::vector<flux::DevSetRows> rows(own);
+        for (size_t m = 0; m < own; m++) {
+            rows[m].pix = c->d_pix + m * c->N;
+            rows[m].disc = c->d_disc + m * c->N;
+            rows[m].hemi = c->d_hemi + m * c->D * c->N * flux::kHemiDoubles;
+            rows[m].gloss = c->d_gloss ? c->d_gloss + m * c->N * 4 : nullptr;
+        }
+        e = hipMemcpy(c->d_setrows, rows.data(), own * sizeof(flux::DevSetRows), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         int code = fail(e == hipErrorOutOfMemory ? FLUX_E_NOMEM : FLUX_E_DEVICE, "flux_ctx_create: %s",
                         hipGetErrorString(e));
@@ -555,6 +570,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.disc = c->d_disc;
     rp.hemi = c->d_hemi;
     rp.gloss = c->d_gloss;
+    rp.set_rows = c->d_setrows;
     rp.rowperm = c->d_rowperm;
     rp.invperm = c->d_invperm;
     rp.stats = nullptr;

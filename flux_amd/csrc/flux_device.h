@@ -163,6 +163,13 @@ struct SetRange {
     uint32_t first, stride, count;
 };
 
+// Where one held sample set's rows of the four sample tables start (abi.hip fills one record per table slot).
+struct DevSetRows {
+    const double2 *pix, *disc;
+    const double *hemi, *gloss;
+};
+static_assert(sizeof(DevSetRows) == 32, "DevSetRows layout");
+
 // Kernel argument block (by value -> kernarg segment -> scalar loads).
 struct RenderParams {
     // camera (trace.rs:44-60, scene.rs:28-35)
@@ -239,6 +246,7 @@ struct RenderParams {
     // living in scalar registers across the pass loop: focal * (Wx, Wy, Wz); pxc[x] = x - half_w, pxc[img_w + row] = (img_h - row) - half_h
     double fwx, fwy, fwz;
     const double *pxc;
+    const DevSetRows *set_rows;  // [slots held]: the rows of pix / disc / hemi / gloss of each held set
 };
 
 }  // namespace flux

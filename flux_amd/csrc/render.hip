@@ -73,6 +73,9 @@
 #ifndef FLUX_SCALAR_VOTES
 #define FLUX_SCALAR_VOTES 1  // wave votes on boolean expressions written as scalar arithmetic on the lane masks of their compares (render_body.inc)
 #endif
+#ifndef FLUX_SET_ROWS
+#define FLUX_SET_ROWS 1  // FAST bounce / split kernel: a set's table rows from the context's DevSetRows record (one scalar load) instead of pointer + set * stride
+#endif
 #ifndef FLUX_SPLIT_UNIFORM_SUB
 #define FLUX_SPLIT_UNIFORM_SUB 1  // render_split_kernel: the wave's index in its block read into a scalar register (cursor / queue count in SGPRs)
 #endif
