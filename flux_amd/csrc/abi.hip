@@ -18,6 +18,7 @@
 #include "../../include/flux_abi.h"
 #include "flux_device.h"
 #include "flux_tables.h"
+#include "flux_math_coeffs.h"  // kExp2Poly -> RenderParams::exp2c
 
 namespace {
 
@@ -571,6 +572,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.hemi = c->d_hemi;
     rp.gloss = c->d_gloss;
     rp.set_rows = c->d_setrows;
+    for (int k = 0; k < 12; k++) rp.exp2c[k] = flux::fastmath::kExp2Poly[k];
     rp.rowperm = c->d_rowperm;
     rp.invperm = c->d_invperm;
     rp.stats = nullptr;

@@ -247,6 +247,9 @@ struct RenderParams {
     double fwx, fwy, fwz;
     const double *pxc;
     const DevSetRows *set_rows;  // [slots held]: the rows of pix / disc / hemi / gloss of each held set
+    // flux_math_coeffs.h kExp2Poly, for the glossy lobe's 2^x (render_body.inc FLUX_EXP2_ARGS): read with two scalar loads where the
+    // literals cost 24 s_mov_b32 per evaluation
+    double exp2c[12];
 };
 
 }  // namespace flux

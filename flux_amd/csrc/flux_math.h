@@ -90,6 +90,15 @@ __device__ __forceinline__ double fexp2(double t) {
     return __builtin_amdgcn_ldexp(p, (int)n);
 }
 
+// fexp2 with the polynomial's coefficients in memory (flux_math_coeffs.h poly_exp2_tab)
+__device__ __forceinline__ double fexp2_tab(double t, const double *c) {
+    t = __builtin_fmax(t, -1100.0);
+    const double n = __builtin_rint(t);
+    const double f = t - n;
+    const double p = poly_exp2_tab(f, c);
+    return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
 // pow(x, y) for x >= 0, y > 0 finite (the render loop's domain: x = 1 - sample.y or a cosine).
 __device__ __forceinline__ double fpow_pos(double x, double y) {
     const double r = fexp2(y * flog2(x));

@@ -73,6 +73,9 @@
 #ifndef FLUX_SCALAR_VOTES
 #define FLUX_SCALAR_VOTES 1  // wave votes on boolean expressions written as scalar arithmetic on the lane masks of their compares (render_body.inc)
 #endif
+#ifndef FLUX_EXP2_ARGS
+#define FLUX_EXP2_ARGS 1  // FAST glossy lobe: the 2^x polynomial's coefficients from the kernel arguments (scalar loads) instead of literals
+#endif
 #ifndef FLUX_SET_ROWS
 #define FLUX_SET_ROWS 1  // FAST bounce / split kernel: a set's table rows from the context's DevSetRows record (one scalar load) instead of pointer + set * stride
 #endif
