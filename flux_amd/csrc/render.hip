@@ -73,6 +73,9 @@
 #ifndef FLUX_SCALAR_VOTES
 #define FLUX_SCALAR_VOTES 1  // wave votes on boolean expressions written as scalar arithmetic on the lane masks of their compares (render_body.inc)
 #endif
+#ifndef FLUX_SPLIT_MAX32
+#define FLUX_SPLIT_MAX32 1  // render_split_kernel: a second instantiation for scenes of at most 32 spheres (one filter group, no group loop)
+#endif
 #ifndef FLUX_EXP2_ARGS
 #define FLUX_EXP2_ARGS 1  // FAST glossy lobe: the 2^x polynomial's coefficients from the kernel arguments (scalar loads) instead of literals
 #endif
