@@ -73,6 +73,9 @@
 #ifndef FLUX_SCALAR_VOTES
 #define FLUX_SCALAR_VOTES 1  // wave votes on boolean expressions written as scalar arithmetic on the lane masks of their compares (render_body.inc)
 #endif
+#ifndef FLUX_SPLIT_TYP
+#define FLUX_SPLIT_TYP 1  // render_split_kernel: a third instantiation with the usual scene's flags as compile-time constants
+#endif
 #ifndef FLUX_SPLIT_MAX32
 #define FLUX_SPLIT_MAX32 1  // render_split_kernel: a second instantiation for scenes of at most 32 spheres (one filter group, no group loop)
 #endif
