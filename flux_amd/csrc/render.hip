@@ -73,6 +73,9 @@
 #ifndef FLUX_SCALAR_VOTES
 #define FLUX_SCALAR_VOTES 1  // wave votes on boolean expressions written as scalar arithmetic on the lane masks of their compares (render_body.inc)
 #endif
+#ifndef FLUX_BVH4_TYP
+#define FLUX_BVH4_TYP 1  // render_bvh4_kernel: an instantiation with the usual analytic set's flags as compile-time constants
+#endif
 #ifndef FLUX_SPLIT_TYP
 #define FLUX_SPLIT_TYP 1  // render_split_kernel: a third instantiation with the usual scene's flags as compile-time constants
 #endif

@@ -14,9 +14,9 @@ spec = importlib.util.spec_from_file_location("_b", os.path.join(ROOT, "flux_amd
 b = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(b)
 
-INST = {"bvh4": "render_bvh4_kernel<false, true>", "bvh4g": "render_bvh4_kernel<false, false>", "bvh": "render_bvh_kernel<false>", "split": "render_split_kernel<false, true, true>", "split32": "render_split_kernel<false, true, false>", "split64": "render_split_kernel<false, false, false>",
+INST = {"bvh4": "render_bvh4_kernel<false, true, true>", "bvh4l": "render_bvh4_kernel<false, true, false>", "bvh4g": "render_bvh4_kernel<false, false, false>", "bvh": "render_bvh_kernel<false>", "split": "render_split_kernel<false, true, true>", "split32": "render_split_kernel<false, true, false>", "split64": "render_split_kernel<false, false, false>",
         "refill": "render_refill_kernel<false, false>", "static": "render_static_kernel<false, false>",
-        "bvh4s": "render_bvh4_kernel<true, true>", "refill_tris": "render_refill_kernel<false, true>", "static_tris": "render_static_kernel<false, true>"}
+        "bvh4s": "render_bvh4_kernel<true, true, true>", "refill_tris": "render_refill_kernel<false, true>", "static_tris": "render_static_kernel<false, true>"}
 args = sys.argv[1:]
 asm_out = None
 if "--asm" in args:
