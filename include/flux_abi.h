@@ -208,8 +208,8 @@ int flux_ctx_set_kernel(flux_ctx *ctx, int variant);
  *       zeros and infinities in its own order (NaN pixels): a scene that has one is rendered with the STRICT arithmetic
  *       whatever this setting says, so the reference's NaN pixels appear exactly (flux_ctx_launch_plan reports the
  *       arithmetic in use).  WHAT THAT COSTS: STRICT renders demo2 at 16384 spp in 0.80 s where FAST
- *       takes 0.23 s, and a mesh scene also loses both traversal kernels -- so `normal: [0, 2, 0]`, or a normal typed to four
- *       digits ([0.7071, 0, 0.7071]: |n|^2 = 0.99997), is a 3.5 x slower scene than the same plane normalised to double
+ *       takes 0.20 s, and a mesh scene also loses both traversal kernels -- so `normal: [0, 2, 0]`, or a normal typed to four
+ *       digits ([0.7071, 0, 0.7071]: |n|^2 = 0.99997), is a 4 x slower scene than the same plane normalised to double
  *       precision.  The test is |n.n - 1| > 4 eps and is not looser on purpose: FAST takes every direction as a unit vector,
  *       and a normal that is off by 3e-5 bends every reflection off it by as much, which is above the parity tolerance.
  *       One exception: where the STRICT arithmetic cannot run the job at all (its LDS recursion stack holds 31 levels of
