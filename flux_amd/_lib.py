@@ -24,7 +24,13 @@ NUM_STATS = 16
 BVH_INFO_WORDS = 16
 PLAN_WORDS = 8
 PLAN_NONE, PLAN_STATIC, PLAN_REFILL, PLAN_SPLIT, PLAN_BVH_BINARY, PLAN_BVH4 = -1, 0, 1, 2, 3, 4
-ABI_VERSION = 2
+CREATE_TIMING_WORDS = 8
+CREATE_TIMING_NAMES = ("total", "host", "runtime", "alloc", "upload", "tables", "free", "other")
+SHARD_AUTO, SHARD_SETS, SHARD_ROWS = 0, 1, 2
+SHARD_LOOPBACK = 0x100
+MULTI_INFO_WORDS = 8
+MULTI_TIMING_WORDS = 8
+ABI_VERSION = 3
 
 
 class FluxMaterial(C.Structure):
@@ -98,6 +104,20 @@ SYMBOLS = {
     "flux_ctx_copy_row_perm": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_int32), C.c_uint64]),
     "flux_ctx_camera_basis": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "flux_ctx_device_bytes": (C.c_uint64, [_P]),
+    "flux_ctx_create_timing": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "flux_multi_create": (C.c_int, [C.POINTER(FluxSceneDesc), C.POINTER(FluxJobCfg), C.c_uint64, C.POINTER(C.c_int), C.c_uint64,
+                                    C.c_int, C.POINTER(_P)]),
+    "flux_multi_destroy": (None, [_P]),
+    "flux_multi_render_frame": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "flux_multi_render_frame_device": (C.c_int, [_P, C.POINTER(_P)]),
+    "flux_multi_set_kernel": (C.c_int, [_P, C.c_int]),
+    "flux_multi_set_math": (C.c_int, [_P, C.c_int]),
+    "flux_multi_ctx": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    "flux_multi_info": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "flux_multi_timing": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "flux_multi_release_comms": (C.c_int, []),
+    "flux_render_frame_multi": (C.c_int, [C.POINTER(FluxSceneDesc), C.POINTER(FluxJobCfg), C.c_uint64, C.POINTER(C.c_int),
+                                          C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     "flux_work_units": (C.c_int64, [C.c_uint64, C.c_uint64, C.POINTER(FluxWorkUnit), C.c_uint64]),
     "flux_write_ppm": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.c_uint64, C.c_uint64,
                                  C.POINTER(C.c_uint8)]),

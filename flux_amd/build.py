@@ -10,13 +10,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "flux_amd", "csrc")
-HIP_SOURCES = ["abi.hip", "tables.hip", "render.hip", "bvh.cpp"]
-HIP_HEADERS = ["flux_device.h", "flux_rng.h", "flux_tables.h", "flux_bvh.h", "flux_math.h", "flux_math_coeffs.h",
+HIP_SOURCES = ["abi.hip", "multi.hip", "tables.hip", "render.hip", "bvh.cpp"]
+HIP_HEADERS = ["flux_ctx.h", "flux_device.h", "flux_rng.h", "flux_tables.h", "flux_bvh.h", "flux_math.h", "flux_math_coeffs.h",
                "render_body.inc"]
 HIP_LIB = os.path.join(ROOT, "flux_amd", "libflux_hip.so")
 
-# -ffp-contract=off: the kernels keep the reference's operation order and never
-# fuse a*b+c (rustc does not contract); see DESIGN.md "Numerics".
+# -ffp-contract=off is the translation units' default: host arithmetic, the table generator and the STRICT render kernels keep
+# the reference's operation order and never fuse a*b+c (rustc does not contract).  The FAST render kernels -- the default
+# arithmetic, FLUX_MATH_FAST -- are compiled under `#pragma clang fp contract(fast)` inside render.hip and DO use FMA; see
+# DESIGN.md "Numerics" for what that changes (ulps) and the parity tests that bound it.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
              "-fno-fast-math", "-Wall", "-Wno-unused-function",
              # machine LICM hoists the ~35 f64 polynomial coefficients of flux_math.h into VGPRs for the

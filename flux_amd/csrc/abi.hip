@@ -7,6 +7,7 @@
 // point fails with FLUX_E_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -20,7 +21,9 @@
 #include "flux_tables.h"
 #include "flux_math_coeffs.h"  // kExp2Poly -> RenderParams::exp2c
 
-namespace {
+#include "flux_ctx.h"
+
+namespace flux {
 
 thread_local std::string g_last_error;
 
@@ -34,68 +37,16 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                       \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail(e_ == hipErrorOutOfMemory ? FLUX_E_NOMEM : FLUX_E_DEVICE, "%s: %s", \
-                        #expr, hipGetErrorString(e_));                                      \
-    } while (0)
+}  // namespace flux
 
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
-}  // namespace
-
-struct flux_ctx {
-    int device = 0;
-    flux::RenderParams rp{};  // camera + table pointers; work fields set per launch
-    uint64_t seed = 0;
-    uint32_t n = 0, N = 0, D = 0, S = 0, W = 0, H = 0;
-    flux::SetRange sets{0, 1, 0};  // sets with tables in this context (all S unless created by flux_ctx_create_sets)
-    flux::DevShape *d_shapes = nullptr;
-    flux::DevMaterial *d_mats = nullptr;
-    unsigned char *d_fscene = nullptr;  // FAST path: scan spheres | scan planes | hit records | f32 filter spheres
-    double2 *d_pix = nullptr, *d_disc = nullptr;
-    double *d_hemi = nullptr;
-    double *d_gloss = nullptr;  // FAST glossy-lobe factors of pixel_sets
-    flux::DevSetRows *d_setrows = nullptr;  // per table slot: where the set's rows of the four tables start
-    int32_t *d_rowperm = nullptr, *d_invperm = nullptr;
-    unsigned long long *d_stats = nullptr;
-    bool stats_on = false;
-    // extension: triangle meshes
-    flux::DevTri *d_tris = nullptr;
-    flux::DevNode *d_nodes = nullptr;
-    flux::DevNode4Q *d_nodes4 = nullptr;
-    flux::DevLeafRec *d_leaves = nullptr;
-    flux::DevNodeQ *d_nodesq = nullptr;
-    flux::BvhInfo bvh{};
-    int traversal = FLUX_TRAVERSE_BVH;
-    int variant = FLUX_KERNEL_DEFAULT;
-    int math = FLUX_MATH_FAST;
-    // scratch framebuffer for the host-output path
-    double *d_out = nullptr;
-    size_t d_out_doubles = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-    uint64_t device_bytes = 0;
-    double U[3], V[3], Wv[3];
-};
+using flux::DeviceGuard;
+using flux::fail;
 
 extern "C" {
 
 uint32_t flux_abi_version(void) { return FLUX_ABI_VERSION; }
 
-const char *flux_last_error(void) { return g_last_error.c_str(); }
+const char *flux_last_error(void) { return flux::g_last_error.c_str(); }
 
 int flux_device_count(void) {
     int n = 0;
@@ -170,6 +121,15 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
                          uint64_t first_set, uint64_t set_stride, flux_ctx **out) {
     if (!scene || !cfg || !out) return fail(FLUX_E_INVALID, "flux_ctx_create: null argument");
     *out = nullptr;
+    // where the wall time of this call goes (flux_ctx_create_timing): lap(k) books the time since the previous lap under word k
+    double laps[FLUX_CREATE_TIMING_WORDS] = {};
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto t_last = t_begin;
+    auto lap = [&](int k) {
+        const auto now = std::chrono::steady_clock::now();
+        laps[k] += std::chrono::duration<double, std::milli>(now - t_last).count();
+        t_last = now;
+    };
     if (set_stride < 1 || first_set >= set_stride)
         return fail(FLUX_E_INVALID, "sample-set share: need set_stride >= 1 and first_set < set_stride, got %llu / %llu",
                     (unsigned long long)first_set, (unsigned long long)set_stride);
@@ -221,6 +181,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     }
     if (total_tris >= (1ull << 27))  // leaf references pack (first << 3 | count) into 31 bits
         return fail(FLUX_E_INVALID, "too many triangles: %llu", (unsigned long long)total_tris);
+    lap(FLUX_CREATE_MS_HOST);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(FLUX_E_DEVICE, "no HIP device visible (this library has no CPU fallback)");
@@ -228,6 +189,8 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
 
     DeviceGuard guard(device);
     if (!guard.ok) return fail(FLUX_E_DEVICE, "hipSetDevice(%d) failed", device);
+    (void)hipFree(nullptr);  // the runtime's lazy per-device initialisation, booked under its own word (zero once the process has used the device)
+    lap(FLUX_CREATE_MS_RUNTIME);
 
     flux_ctx *c = new (std::nothrow) flux_ctx();
     if (!c) return fail(FLUX_E_NOMEM, "host allocation failed");
@@ -482,6 +445,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.nsamp = c->N;
     rp.num_sets = c->S;
 
+    lap(FLUX_CREATE_MS_HOST);
     // ---- HBM allocations ------------------------------------------------------
     const size_t own = c->sets.count ? c->sets.count : 1;  // a share past the last set holds nothing (allocate one slot)
     const size_t pix_bytes = own * c->N * sizeof(double2);
@@ -490,8 +454,10 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) {
         if (e != hipSuccess) return;
+        lap(FLUX_CREATE_MS_UPLOAD);
         e = hipMalloc(p, bytes);
         if (e == hipSuccess) c->device_bytes += bytes;
+        lap(FLUX_CREATE_MS_ALLOC);
     };
     alloc((void **)&c->d_shapes, shapes.size() * sizeof(flux::DevShape));
     // the materials, followed by their bounce weights {f * (n.wi)/pdf in FAST's closed form: f / INV_PI for Matte, f otherwise; pad}
@@ -538,15 +504,23 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     if (e == hipSuccess) e = hipMemcpy(c->d_mats + mats.size(), wtab.data(), wtab.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_fscene, fscene.data(), fscene.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(c->d_stats, 0, FLUX_NUM_STATS * sizeof(unsigned long long));
+    lap(FLUX_CREATE_MS_UPLOAD);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    lap(FLUX_CREATE_MS_OTHER);
     // ---- MasterSampleSets::new on the device (sampling.rs:13-33) --------------
+    double tab_ms[3] = {0, 0, 0};
     if (e == hipSuccess)
-        e = flux::generate_tables(seed, c->S, c->sets, c->D, c->n, c->H, c->d_pix, c->d_disc, c->d_hemi, c->d_rowperm, c->d_invperm, nullptr);
+        e = flux::generate_tables(seed, c->S, c->sets, c->D, c->n, c->H, c->d_pix, c->d_disc, c->d_hemi, c->d_rowperm, c->d_invperm, nullptr, tab_ms);
     if (e == hipSuccess && FLUX_GLOSS_TABLE) {
         e = flux::generate_gloss_table(c->d_pix, (size_t)c->sets.count * c->N, c->d_gloss, nullptr);
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     }
+    lap(FLUX_CREATE_MS_TABLES);
+    // the generator's scratch (the permutations of every grid: 262 MB at 16384 spp) is allocation, not table work
+    laps[FLUX_CREATE_MS_TABLES] -= tab_ms[0] + tab_ms[2];
+    laps[FLUX_CREATE_MS_ALLOC] += tab_ms[0];
+    laps[FLUX_CREATE_MS_FREE] += tab_ms[2];
     if (e == hipSuccess) {
         // where each held set's rows of the sample tables start: one 32-B record per slot, so that a kernel forms a table address with one
         // scalar load instead of a 64-bit multiply-add chain per table and pass (render_body.inc FLUX_SET_ROWS)
@@ -636,6 +610,9 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         if (!(std::fabs(sp.px) < 1e3 && std::fabs(sp.py) < 1e3 && std::fabs(sp.pz) < 1e3 && sp.rr < 1e6)) rp.self_skip = 0;
     rp.n_sph = (int32_t)fsph.size();
     rp.n_pln = (int32_t)fpln.size();
+    lap(FLUX_CREATE_MS_UPLOAD);
+    laps[FLUX_CREATE_MS_TOTAL] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    for (int k = 0; k < FLUX_CREATE_TIMING_WORDS; k++) c->create_ms[k] = laps[k];
     *out = c;
     return FLUX_OK;
 }
@@ -1023,6 +1000,12 @@ int flux_ctx_camera_basis(flux_ctx *ctx, double uvw[9]) {
 }
 
 uint64_t flux_ctx_device_bytes(flux_ctx *ctx) { return ctx ? ctx->device_bytes : 0; }
+
+int flux_ctx_create_timing(flux_ctx *ctx, double out_ms[FLUX_CREATE_TIMING_WORDS]) {
+    if (!ctx || !out_ms) return fail(FLUX_E_INVALID, "null argument");
+    for (int k = 0; k < FLUX_CREATE_TIMING_WORDS; k++) out_ms[k] = ctx->create_ms[k];
+    return FLUX_OK;
+}
 
 // ---- host-side pieces of the boundary ------------------------------------------
 

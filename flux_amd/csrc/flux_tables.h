@@ -8,10 +8,10 @@ namespace flux {
 
 // MasterSampleSets::new (sampling.rs:13-33) for the sets of `sets` (slot m = global set first + m * stride; all S of
 // them for {0, 1, S}) + shuffle_indices for all H rows and all S sets (sampling.rs:35-40), generated on the device.
-// Synchronises `stream`.
+// Synchronises `stream`.  phase_ms (optional) += {scratch allocation, launches + wait, scratch release} in ms.
 hipError_t generate_tables(uint64_t seed, uint32_t S, SetRange sets, uint32_t D, uint32_t n, uint32_t H,
                            double2 *pix, double2 *disc, double *hemi, int32_t *rowperm, int32_t *invperm,
-                           hipStream_t stream);
+                           hipStream_t stream, double *phase_ms = nullptr);
 // One set of a samplers-crate generator (0 regular, 1 jittered, 2 multi-jittered, 3 correlated MJ) and,
 // if d_hemi != nullptr, its to_hemisphere(.., 0.0) image [N][3].  Synchronises `stream`.
 hipError_t generate_sampler_grid(int kind, uint64_t seed, uint32_t n, double *d_xy, double *d_hemi,

@@ -12,6 +12,8 @@
 // with py_i the y-permutation used for row i and px_k the x-permutation used
 // for column k (one shared pair for the correlated variant, lib.rs:75-90).
 // The permutations are drawn first by one thread each (shuffle kernel).
+#include <chrono>
+
 #include "flux_device.h"
 #include "flux_rng.h"
 #include "flux_tables.h"
@@ -236,8 +238,14 @@ hipError_t generate_sampler_grid(int kind, uint64_t seed, uint32_t n, double *d_
 
 hipError_t generate_tables(uint64_t seed, uint32_t S, SetRange sets, uint32_t D, uint32_t n, uint32_t H,
                            double2 *pix, double2 *disc, double *hemi, int32_t *rowperm, int32_t *invperm,
-                           hipStream_t stream) {
+                           hipStream_t stream, double *phase_ms) {
     const size_t N = (size_t)n * n;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](int k) {  // phase_ms[0] scratch allocation, [1] launches + the wait for the kernels, [2] scratch release
+        const auto now = std::chrono::steady_clock::now();
+        if (phase_ms) phase_ms[k] += std::chrono::duration<double, std::milli>(now - t_last).count();
+        t_last = now;
+    };
     const uint32_t So = sets.count;  // sets held by this context
     uint16_t *cmj_perms = nullptr, *mj_perms = nullptr;
     hipError_t e;
@@ -246,6 +254,7 @@ hipError_t generate_tables(uint64_t seed, uint32_t S, SetRange sets, uint32_t D,
         inv_perm_kernel<<<blocks_for((size_t)H * S, 256), 256, 0, stream>>>(H, S, rowperm, invperm);
         e = hipGetLastError();
         const hipError_t e2 = hipStreamSynchronize(stream);
+        lap(1);
         return e != hipSuccess ? e : e2;
     }
     size_t cmj_elems = (size_t)So * 2 * n;
@@ -257,6 +266,7 @@ hipError_t generate_tables(uint64_t seed, uint32_t S, SetRange sets, uint32_t D,
     }
     uint16_t *pix_perms = cmj_perms, *disc_perms = cmj_perms + cmj_elems;
     const unsigned bs = 256;
+    lap(0);
     cmj_perm_kernel<<<blocks_for((size_t)So * 2, 64), 64, 0, stream>>>(seed, kKindPixel, sets, n, pix_perms);
     cmj_perm_kernel<<<blocks_for((size_t)So * 2, 64), 64, 0, stream>>>(seed, kKindDisc, sets, n, disc_perms);
     mj_perm_kernel<<<blocks_for((size_t)So * D * 2 * n, bs), bs, 0, stream>>>(seed, sets, D, n, mj_perms);
@@ -267,8 +277,10 @@ hipError_t generate_tables(uint64_t seed, uint32_t S, SetRange sets, uint32_t D,
     hemi_fill_kernel<<<blocks_for((size_t)So * D * N, bs), bs, 0, stream>>>(seed, sets, D, n, mj_perms, hemi);
     e = hipGetLastError();
     hipError_t e2 = hipStreamSynchronize(stream);
+    lap(1);
     (void)hipFree(cmj_perms);
     (void)hipFree(mj_perms);
+    lap(2);
     return e != hipSuccess ? e : e2;
 }
 

@@ -5,7 +5,12 @@
 // wait (:92-94), ImageBuilder writes "<scene_name>.ppm" into the cwd and prints the total time
 // (manager.rs:326-335).  -n/--node ADDRESS[:PORT] adds NetworkWorkers (flux_node processes, flux_net.hpp) and
 // -L leaves the local GPUs out, as in main.rs:37-66.  Additions: --seed (the reference seeds from OS
-// entropy), --gpus, --outdir.  Not carried over: -g (SDL preview), rejected.
+// entropy), --gpus, --outdir, --split.  Not carried over: -g (SDL preview), rejected.
+//
+// --split sets|rows|units: how the local GPUs share a frame.  `units` is the reference's scheme -- one worker per device pulling
+// WorkUnits from the shared channel (manager.rs:100) --, `sets` / `rows` hand the node's GPUs to ONE MultiGpuWorker (flux_multi_*:
+// per-device contexts with 1/G of the tables, one launch per device, one RCCL all-gather).  Default: sets (rows below 64 spp) when
+// two or more local GPUs are the whole pool, units otherwise (a pool with network nodes needs the shared channel's balancing).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +41,7 @@ struct Config {  // flux/src/main.rs:115-124
     uint64_t seed = 1;
     int gpus = -1;
     std::string outdir = ".";
+    std::string split = "auto";
 };
 
 void usage() {
@@ -50,7 +56,8 @@ void usage() {
                  "    -t, --threads <N>            CPU rendering threads (accepted, unused)\n"
                  "        --seed <SEED>            RNG seed [default 1]\n"
                  "        --gpus <N>               number of GPUs to use [default: all]\n"
-                 "        --outdir <DIR>           where <scene_name>.ppm is written [default .]\n");
+                 "        --outdir <DIR>           where <scene_name>.ppm is written [default .]\n"
+                 "        --split <sets|rows|units> how the local GPUs share a frame [default: sets for >= 2 GPUs without nodes, else units]\n");
 }
 
 size_t parse_usize(const char *flag, const char *v) {
@@ -98,6 +105,12 @@ Config config_from_args(int argc, char **argv) {
             c.gpus = (int)parse_usize("--gpus", need("--gpus"));
         } else if (a == "--outdir") {
             c.outdir = need("--outdir");
+        } else if (a == "--split") {
+            c.split = need("--split");
+            if (c.split != "sets" && c.split != "rows" && c.split != "units" && c.split != "auto") {
+                std::fprintf(stderr, "error: invalid value '%s' for '--split' (sets, rows, units)\n", c.split.c_str());
+                std::exit(2);
+            }
         } else if (!a.empty() && a[0] == '-') {
             std::fprintf(stderr, "error: Found argument '%s' which wasn't expected\n", a.c_str());
             std::exit(2);
@@ -141,9 +154,27 @@ int main(int argc, char **argv) {
 
     std::vector<std::unique_ptr<Worker>> workers;
     std::vector<WorkerHandle> handles;
-    for (int d = 0; d < ndev; d++) {
-        workers.emplace_back(new GpuWorker(d, config.seed));
+    std::string split = config.split;
+    if (split == "auto") split = (ndev >= 2 && config.network_workers.empty()) ? "sets" : "units";
+    if (split != "units" && !config.network_workers.empty()) {
+        std::fprintf(stderr, "error: --split %s renders whole frames on the local GPUs and cannot share a job with -n nodes; use --split units\n",
+                     split.c_str());
+        return 2;
+    }
+    MultiGpuWorker *multi = nullptr;
+    if (split != "units" && ndev >= 1) {
+        std::vector<int> devs;
+        for (int d = 0; d < ndev; d++) devs.push_back(d);
+        // (sets need 64 spp: below that the library's AUTO picks rows)
+        const int shard = split == "rows" ? FLUX_SHARD_ROWS : (config.sample_root * config.sample_root >= 64 ? FLUX_SHARD_SETS : FLUX_SHARD_AUTO);
+        multi = new MultiGpuWorker(devs, config.seed, shard);
+        workers.emplace_back(multi);
         handles.push_back(workers.back()->handle());
+    } else {
+        for (int d = 0; d < ndev; d++) {
+            workers.emplace_back(new GpuWorker(d, config.seed));
+            handles.push_back(workers.back()->handle());
+        }
     }
     for (const std::string &endpoint : config.network_workers) {
         std::printf("Connecting to worker %s\n", endpoint.c_str());
@@ -161,6 +192,7 @@ int main(int argc, char **argv) {
     }
     std::printf("Rendering %s with %d GPU worker(s) and %zu network node(s), sample root %zu, depth %zu, %zu rows per work unit\n",
                 s.scene_name.c_str(), ndev, config.network_workers.size(), config.sample_root, config.max_depth, config.rows_per_work_unit);
+    if (multi) std::printf("The %d local GPU(s) render whole frames as one worker (--split %s: one launch per device, one RCCL all-gather)\n", ndev, split.c_str());
 
     // flux/src/main.rs:70-111: manager, image builder, schedule one job, wait, shut everything down
     ImageBuilder image_builder;
@@ -177,7 +209,14 @@ int main(int argc, char **argv) {
         manager.stop();
     }
     image_builder.stop();
+    if (multi) {
+        const std::vector<double> t = multi->last_timing();
+        if (t.size() >= 8)
+            std::printf("multi-GPU frame: create %.1f ms (slowest context %.1f, communicators %.1f), frame %.1f ms (kernel %.1f, all-gather %.2f, "
+                        "reassembly %.2f, copy %.2f)\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+    }
     for (auto &w : workers) w->stop();
+    flux_multi_release_comms();
     if (GpuWorker::failures() > 0) {
         std::fprintf(stderr, "error: %d job(s) / work unit(s) were abandoned by a GPU worker; the image is incomplete\n",
                      GpuWorker::failures());

@@ -228,6 +228,7 @@ void GpuWorker::stop() {  // workers.rs:95-98: send(None), join
 
 std::atomic<int> GpuWorker::worker_failures_{0};
 int GpuWorker::failures() { return worker_failures_.load(); }
+void GpuWorker::note_failure() { worker_failures_.fetch_add(1); }
 
 void GpuWorker::run() {
     // 'main: while let Ok(Some((job, recv_unit, send_result, wg))) = r.recv()   (workers.rs:43)
@@ -292,6 +293,91 @@ void GpuWorker::run() {
         }
         flux_ctx_destroy(ctx);
         req.wg->done();  // drop(wg)   (workers.rs:74)
+    }
+}
+
+// ---- MultiGpuWorker: the node's GPUs as one worker (flux_multi_*) ----------------------------------
+MultiGpuWorker::MultiGpuWorker(std::vector<int> devices, uint64_t seed, int shard)
+    : devices_(std::move(devices)), seed_(seed), shard_(shard), sender_(std::make_shared<Channel<std::optional<WorkerRequest>>>()) {
+    thread_ = std::thread([this] { run(); });
+}
+
+MultiGpuWorker::~MultiGpuWorker() { stop(); }
+
+void MultiGpuWorker::stop() {
+    if (stopped_) return;
+    stopped_ = true;
+    sender_->send(std::nullopt);
+    if (thread_.joinable()) thread_.join();
+}
+
+std::vector<double> MultiGpuWorker::last_timing() const {
+    std::lock_guard<std::mutex> g(mu_);
+    return timing_;
+}
+
+void MultiGpuWorker::run() {
+    for (;;) {
+        auto msg = sender_->recv();
+        if (!msg || !*msg) break;
+        WorkerRequest req = std::move(**msg);
+        // Scene::from_data + Camera::new on every device (workers.rs:46-54), concurrently, + the communicators
+        AbiScene abi(req.job->scene_data);
+        flux_job_cfg cfg{req.job->config.sample_root, req.job->config.max_trace_depth, req.job->config.rows_per_work_unit};
+        flux_multi *m = nullptr;
+        if (flux_multi_create(&abi.desc, &cfg, seed_, devices_.data(), devices_.size(), shard_, &m) != FLUX_OK) {
+            std::fprintf(stderr, "MultiGpuWorker(%zu devices): %s\n", devices_.size(), flux_last_error());
+            GpuWorker::note_failure();
+            req.wg->done();
+            continue;
+        }
+        const size_t w = req.job->scene_data.output_settings.image_width;
+        const size_t h = req.job->scene_data.output_settings.image_height;
+        std::vector<double> frame;
+        bool failed = false;
+        while (auto unit = req.recv_unit->recv()) {
+            if (unit->row_end < unit->row_start) {  // renders as no rows in the reference (trace.rs:62)
+                RenderEvent ev;
+                ev.kind = RenderEvent::RowsReady;
+                ev.result.work_unit = *unit;
+                req.send_result->send(std::move(ev));
+                continue;
+            }
+            if (unit->row_end >= h) {
+                std::fprintf(stderr, "MultiGpuWorker: work unit rows [%zu,%zu] outside image height %zu\n", (size_t)unit->row_start,
+                             (size_t)unit->row_end, h);
+                GpuWorker::note_failure();
+                break;
+            }
+            if (frame.empty() && !failed) {  // the first unit: camera.render for the whole image, on all devices (workers.rs:60)
+                frame.resize(w * h * 3);
+                if (flux_multi_render_frame(m, frame.data()) != FLUX_OK) {
+                    std::fprintf(stderr, "MultiGpuWorker(%zu devices): %s\n", devices_.size(), flux_last_error());
+                    GpuWorker::note_failure();
+                    failed = true;
+                }
+                double t[FLUX_MULTI_TIMING_WORDS];
+                if (!failed && flux_multi_timing(m, t) == FLUX_OK) {
+                    std::lock_guard<std::mutex> g(mu_);
+                    timing_.assign(t, t + FLUX_MULTI_TIMING_WORDS);
+                }
+            }
+            if (failed) break;
+            const size_t nrows = unit->row_end - unit->row_start + 1;
+            RenderEvent ev;
+            ev.kind = RenderEvent::RowsReady;
+            ev.result.work_unit = *unit;
+            ev.result.rows.resize(nrows);
+            for (size_t r = 0; r < nrows; r++) {
+                auto &row = ev.result.rows[r];
+                row.resize(w);
+                const double *p = frame.data() + (unit->row_start + r) * w * 3;
+                for (size_t c = 0; c < w; c++) row[c] = Color{p[3 * c], p[3 * c + 1], p[3 * c + 2]};
+            }
+            req.send_result->send(std::move(ev));
+        }
+        flux_multi_destroy(m);
+        req.wg->done();
     }
 }
 

@@ -181,6 +181,7 @@ public:
     // jobs / work units any GpuWorker of this process had to give up (context creation or a render call failed, or a
     // unit was out of range): the reference panics there (workers.rs:78); the front-ends exit non-zero when this is > 0
     static int failures();
+    static void note_failure();  // (MultiGpuWorker books its failures in the same counter)
 private:
     void run();
     static std::atomic<int> worker_failures_;
@@ -189,6 +190,34 @@ private:
     std::shared_ptr<Channel<std::optional<WorkerRequest>>> sender_;
     std::thread thread_;
     bool stopped_ = false;
+};
+
+// The GPUs of this node as ONE worker behind the same trait: per job it creates a flux_multi (include/flux_abi.h: one context per
+// device holding its share of the sample tables, created concurrently) and, when the first work unit arrives, renders the WHOLE frame
+// with one launch per device and one RCCL all-gather; every unit it pulls from the shared channel (workers.rs:56) is then answered
+// from that frame.  Against one GpuWorker per device -- each building ALL tables and pulling fifty-row units (12 units over 8 GPUs: two
+// rounds, 75 % at best), each unit copied back through the host -- the frame costs one balanced launch and one device-side gather.
+// It renders every row itself, so it is for a pool WITHOUT other workers (flux_cli.cpp selects it only then): rows a NetworkWorker
+// renders as well would be work done twice.
+class MultiGpuWorker : public Worker {
+public:
+    MultiGpuWorker(std::vector<int> devices, uint64_t seed, int shard = FLUX_SHARD_AUTO);
+    ~MultiGpuWorker() override;
+    WorkerHandle handle() const override { return WorkerHandle(sender_); }
+    void stop() override;
+    WorkerInfo info() const override { return WorkerInfo{devices_.size()}; }
+    // ms of the most recent job: flux_multi_timing's words (create, slowest context, communicators, frame, kernel, gather, reassembly, copy)
+    std::vector<double> last_timing() const;
+private:
+    void run();
+    std::vector<int> devices_;
+    uint64_t seed_;
+    int shard_;
+    std::shared_ptr<Channel<std::optional<WorkerRequest>>> sender_;
+    std::thread thread_;
+    bool stopped_ = false;
+    mutable std::mutex mu_;
+    std::vector<double> timing_;
 };
 
 // ImageBuilder (manager.rs:278-363): assembles RowsReady rows, prints the total time and writes

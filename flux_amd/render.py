@@ -210,6 +210,107 @@ class Renderer:
     def device_bytes(self) -> int:
         return int(_lib.lib.flux_ctx_device_bytes(self._handle()))
 
+    def create_timing(self) -> dict:
+        """Where the wall time of this context's creation went, in ms (flux_ctx_create_timing): total, host, runtime,
+        alloc, upload, tables, free, other -- the span the reference's timer includes (manager.rs:145 -> 170)."""
+        return _create_timing(self._handle())
+
+
+def _create_timing(handle) -> dict:
+    buf = (C.c_double * _lib.CREATE_TIMING_WORDS)()
+    _lib.check(_lib.lib.flux_ctx_create_timing(handle, buf))
+    return dict(zip(_lib.CREATE_TIMING_NAMES, [float(x) for x in buf]))
+
+
+class MultiRenderer:
+    """One frame on several GPUs of THIS process through the C ABI (flux_multi_*): the job's fan-out to its workers
+    (fluxcore/src/manager.rs:156-162) as one context per device, each holding its share of the sample tables, and ImageBuilder's
+    gather (manager.rs:316-324) as ONE ncclAllGather (RCCL) + a reassembly kernel on devices[0].  No torch.distributed."""
+
+    def __init__(self, scene_data: SceneData, config: JobConfiguration, seed: int = 1, devices=(0,), shard: int = _lib.SHARD_AUTO):
+        self.scene_data, self.config, self.seed = scene_data, config, int(seed)
+        self.devices = [int(d) for d in devices]
+        self.width = scene_data.output_settings.image_width
+        self.height = scene_data.output_settings.image_height
+        self._desc = SceneDesc(scene_data)
+        cfg = _lib.FluxJobCfg(config.sample_root, config.max_trace_depth, config.rows_per_work_unit)
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        _lib.check(_lib.lib.flux_multi_create(C.byref(self._desc.desc), C.byref(cfg), C.c_uint64(self.seed), devs, len(self.devices),
+                                              int(shard), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib.flux_multi_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _handle(self):
+        if not self._h:
+            raise _lib.FluxError(_lib.E_INVALID, "multi renderer is closed")
+        return self._h
+
+    def render_frame(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), dtype=np.float64)
+        _lib.check(_lib.lib.flux_multi_render_frame(self._handle(), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def render_frame_device(self) -> int:
+        """The frame left on devices[0]: its device address ([H][W][3] f64), valid until the next render call."""
+        p = C.c_void_p()
+        _lib.check(_lib.lib.flux_multi_render_frame_device(self._handle(), C.byref(p)))
+        return int(p.value)
+
+    def set_kernel(self, variant: int):
+        _lib.check(_lib.lib.flux_multi_set_kernel(self._handle(), variant))
+
+    def set_math(self, mode: int):
+        _lib.check(_lib.lib.flux_multi_set_math(self._handle(), mode))
+
+    def info(self) -> dict:
+        buf = (C.c_uint64 * _lib.MULTI_INFO_WORDS)()
+        _lib.check(_lib.lib.flux_multi_info(self._handle(), buf))
+        names = ("devices", "shard", "rccl_version", "share_doubles", "ctx_bytes", "buffer_bytes", "comms_cached")
+        return dict(zip(names, [int(x) for x in buf]))
+
+    def timing(self) -> dict:
+        buf = (C.c_double * _lib.MULTI_TIMING_WORDS)()
+        _lib.check(_lib.lib.flux_multi_timing(self._handle(), buf))
+        names = ("create_ms", "ctx_create_ms", "comm_init_ms", "frame_ms", "kernel_ms", "all_gather_ms", "reassembly_ms", "d2h_ms")
+        return dict(zip(names, [float(x) for x in buf]))
+
+    def rank_create_timing(self, rank: int = 0) -> dict:
+        h = C.c_void_p()
+        _lib.check(_lib.lib.flux_multi_ctx(self._handle(), rank, C.byref(h)))
+        return _create_timing(h)
+
+
+def render_frame_multi(scene_data: SceneData, config: JobConfiguration, seed: int = 1, num_devices: int = 0,
+                       shard: int = _lib.SHARD_AUTO) -> np.ndarray:
+    """flux_render_frame_multi: create + render + destroy on the first `num_devices` devices (0 = all)."""
+    desc = SceneDesc(scene_data)
+    cfg = _lib.FluxJobCfg(config.sample_root, config.max_trace_depth, config.rows_per_work_unit)
+    out = np.empty((scene_data.output_settings.image_height, scene_data.output_settings.image_width, 3), dtype=np.float64)
+    _lib.check(_lib.lib.flux_render_frame_multi(C.byref(desc.desc), C.byref(cfg), C.c_uint64(int(seed)), None, num_devices, int(shard),
+                                                out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def release_comms() -> int:
+    return int(_lib.lib.flux_multi_release_comms())
+
 
 def work_units(image_height: int, rows_per_work_unit: int):
     """Job::work_units (job.rs:65-88) through the C ABI."""

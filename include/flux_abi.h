@@ -30,8 +30,9 @@ extern "C" {
 #endif
 
 /* 2: flux_ctx_bvh_info writes FLUX_BVH_INFO_WORDS = 16 words (version 1 documented 8) and takes the caller's capacity;
- *    flux_ctx_launch_plan added. */
-#define FLUX_ABI_VERSION 2
+ *    flux_ctx_launch_plan added.
+ * 3: the multi-GPU frame (flux_multi_*, flux_render_frame_multi) and flux_ctx_create_timing added. */
+#define FLUX_ABI_VERSION 3
 
 /* error codes */
 #define FLUX_OK 0
@@ -281,6 +282,25 @@ int flux_ctx_camera_basis(flux_ctx *ctx, double uvw[9]); /* CameraBasis::new sce
 /* bytes of HBM held by the context's tables + scene */
 uint64_t flux_ctx_device_bytes(flux_ctx *ctx);
 
+/* Where the wall time of the flux_ctx_create* call that made this context went, in milliseconds.  The reference's timer
+ * (manager.rs:145 -> 170) spans exactly this work -- Scene::from_data + Camera::new incl. MasterSampleSets::new run
+ * inside it (workers.rs:46-54) -- so it is reported beside the render time (bench.py `reference_equivalent_s`).
+ * out[FLUX_CREATE_MS_*]: TOTAL = the whole call; HOST = validation, scene records, BVH build (host arithmetic);
+ * RUNTIME = device selection + the HIP runtime's lazy per-device initialisation (zero in a process that has used the
+ * device before); ALLOC = device allocation; UPLOAD = host -> device copies of the scene; TABLES = the sample-table
+ * kernels (MasterSampleSets::new, sampling.rs:13-33) incl. the wait for them; FREE = release of the generator's
+ * scratch; OTHER = events and the rest.  The parts sum to TOTAL. */
+#define FLUX_CREATE_MS_TOTAL 0
+#define FLUX_CREATE_MS_HOST 1
+#define FLUX_CREATE_MS_RUNTIME 2
+#define FLUX_CREATE_MS_ALLOC 3
+#define FLUX_CREATE_MS_UPLOAD 4
+#define FLUX_CREATE_MS_TABLES 5
+#define FLUX_CREATE_MS_FREE 6
+#define FLUX_CREATE_MS_OTHER 7
+#define FLUX_CREATE_TIMING_WORDS 8
+int flux_ctx_create_timing(flux_ctx *ctx, double out_ms[FLUX_CREATE_TIMING_WORDS]);
+
 /* The samplers crate's four generators, evaluated on the device (what sampler-debug plots,
  * sampler-debug/src/main.rs:48-57): kind 0 grid_regular (samplers/src/lib.rs:184-191), 1 grid_jittered
  * (lib.rs:35-44), 2 grid_multi_jittered (lib.rs:64-73; equals hemi-stream set 0 depth 0 before the
@@ -305,6 +325,82 @@ int flux_debug_shade(flux_ctx *ctx, uint64_t n, const double *rays, uint64_t dep
  * host pointer out; b may be NULL for unary functions).  fn: 0 frsqrt, 1 fsqrt, 2 fdiv, 3 flog2,
  * 4 fexp2, 5 fpow_pos, 6 sin(2 pi a), 7 cos(2 pi a), 8 raw v_rsq_f64, 9 raw v_rcp_f64. */
 int flux_debug_fastmath(int device, int fn, const double *a, const double *b, double *out, uint64_t n);
+
+/* ---- one frame on the GPUs of one node ------------------------------------------------------------------------------
+ * Replaces, for GPUs in ONE process, what RenderManager does with a job: the fan-out of the job to every worker
+ * (fluxcore/src/manager.rs:156-162: one clone of the job per worker handle) and ImageBuilder's gather of their rows into
+ * the image (manager.rs:316-324).  Here the fan-out is one context per device -- each holding ONLY its share of the
+ * sample tables (flux_ctx_create_sets(g, G): 1/G of MasterSampleSets::new's work and memory) -- and the gather is ONE
+ * collective, ncclAllGather (RCCL, over xGMI between the GPUs of a node) of the shares, after which the frame is
+ * reassembled ON THE DEVICE by the row permutation and copied to the caller once.  The frame is bit-identical for every
+ * number of devices and equal to flux_render_rows' (a pixel's value depends on (seed, row, column) only).
+ *
+ * How the frame is split (`shard`):
+ *   FLUX_SHARD_SETS: rank g renders, in every row, the pixels whose sample set s has s mod G == g
+ *       (flux_render_sets_device): one pixel per row per owned set, i.e. a 1/G share with the cost of an average pixel;
+ *       needs sample_root^2 >= 64.  Measured 98 % of ideal at G = 8.
+ *   FLUX_SHARD_ROWS: rank g renders rows g, g + G, ... (flux_render_rows_device with row_stride G) -- the reference's
+ *       WorkUnit rows, interleaved; every rank then holds ALL sample tables.
+ *   FLUX_SHARD_AUTO: sets where they apply, rows below 64 spp.
+ *
+ * RCCL is bound at run time (dlopen of librccl.so.1; an RCCL the process has already mapped -- PyTorch's -- is used as
+ * it is), so the library has no link-time dependency on it; flux_multi_create fails with FLUX_E_DEVICE when none is
+ * found.  The communicators of a device list are created once per process (ncclCommInitAll) and kept for later
+ * flux_multi_create calls on the same list; flux_multi_release_comms() destroys them.
+ * Threading: a flux_multi is used by one host thread at a time. */
+#define FLUX_SHARD_AUTO 0
+#define FLUX_SHARD_SETS 1
+#define FLUX_SHARD_ROWS 2
+/* Test hook, OR-ed into `shard`: the ranks may share devices (the same ordinal listed several times) and the all-gather is
+ * replaced by device-to-device copies -- no RCCL is loaded or called.  Every other step (per-rank share contexts, launches,
+ * padding, reassembly) is the product path, so G = 2, 3, 8 can be checked on a one-GPU box. */
+#define FLUX_SHARD_LOOPBACK 0x100
+
+typedef struct flux_multi flux_multi;
+
+/* devices[0..num_devices): HIP device ordinals, all different; devices[0] assembles the frame.  The contexts are
+ * created concurrently (one host thread per device) while the communicators come up. */
+int flux_multi_create(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint64_t seed, const int *devices,
+                      uint64_t num_devices, int shard, flux_multi **out);
+void flux_multi_destroy(flux_multi *m); /* NULL is a no-op */
+
+/* Camera::render for the WHOLE image (every WorkUnit of Job::work_units at once) on all devices: writes
+ * image_height * image_width * 3 doubles, row-major RGB, averaged and max_to_one-clamped (what ImageBuilder holds after
+ * the last RowsReady, manager.rs:316-324).  Synchronous.  out_rgb is caller-owned host memory. */
+int flux_multi_render_frame(flux_multi *m, double *out_rgb);
+/* The same frame left in HBM: *d_frame_rgb points at image_height * image_width * 3 doubles on devices[0], valid until
+ * the next render call on `m` or its destruction.  Synchronous (returns once every device has finished the gather). */
+int flux_multi_render_frame_device(flux_multi *m, const void **d_frame_rgb);
+
+/* flux_ctx_set_kernel / flux_ctx_set_math for every rank's context */
+int flux_multi_set_kernel(flux_multi *m, int variant);
+int flux_multi_set_math(flux_multi *m, int mode);
+/* rank's context, borrowed (owned by `m`): for flux_ctx_launch_plan, statistics, tables */
+int flux_multi_ctx(flux_multi *m, uint64_t rank, flux_ctx **ctx);
+
+/* out[0] devices G, [1] the split in use (FLUX_SHARD_SETS / FLUX_SHARD_ROWS), [2] RCCL version code (ncclGetVersion),
+ * [3] doubles each rank contributes to the all-gather (H * ceil(S / G) * 3 or ceil(H / G) * W * 3), [4] bytes of HBM held
+ * by all ranks' contexts together, [5] bytes of the gather + frame buffers on all devices, [6] 1 if the communicators
+ * were taken from the process-wide cache (an earlier flux_multi_create on the same device list), [7] reserved (0). */
+#define FLUX_MULTI_INFO_WORDS 8
+int flux_multi_info(flux_multi *m, uint64_t out[FLUX_MULTI_INFO_WORDS]);
+
+/* Milliseconds.  [0] flux_multi_create wall time, [1] of it: the slowest rank's flux_ctx_create_sets, [2] of it:
+ * communicator creation (0 when cached; runs beside the context creation), then of the most recent frame: [3] wall time of
+ * the render call, [4] the slowest rank's render kernel (HIP events on its stream), [5] all-gather (events on devices[0]'s
+ * stream: from its own kernel's end, so it includes the wait for slower ranks), [6] reassembly kernel, [7] device -> host
+ * copy of the frame (0 for flux_multi_render_frame_device). */
+#define FLUX_MULTI_TIMING_WORDS 8
+int flux_multi_timing(flux_multi *m, double out_ms[FLUX_MULTI_TIMING_WORDS]);
+
+/* Destroys the process-wide communicator cache (ncclCommDestroy); call when no flux_multi is alive.  Returns the number of
+ * device lists released.  Never fails. */
+int flux_multi_release_comms(void);
+
+/* One call: flux_multi_create + flux_multi_render_frame + flux_multi_destroy (a job's whole life, manager.rs:145-170).
+ * devices may be NULL: the first num_devices devices (num_devices == 0: all visible ones). */
+int flux_render_frame_multi(const flux_scene_desc *scene, const flux_job_cfg *cfg, uint64_t seed, const int *devices,
+                            uint64_t num_devices, int shard, double *out_rgb);
 
 /* Job::work_units (job.rs:65-88), including its `i < H-1` loop guard.  Writes
  * at most `cap` units and returns the number the reference would issue, or a

@@ -5,7 +5,13 @@
  * job.rs:65-88), and writes the raw f64 RGB frame to `out`.  tests/test_gpu_abi_client.py builds this with gcc, runs it
  * and compares the file bit for bit with the Python binding's render of the same scene.
  *
- *   abi_c_client <out.bin> <width> <height> <sample_root> <seed> <rows_per_unit>
+ *   abi_c_client <out.bin> <width> <height> <sample_root> <seed> <rows_per_unit> [multi <G> <shard>]
+ *
+ * With `multi G shard` the frame written to `out` comes from the multi-GPU entry instead (flux_multi_create on devices
+ * 0..G-1 + flux_multi_render_frame: per-device contexts, one launch each, ONE ncclAllGather over RCCL, reassembly on
+ * devices[0]) -- the counterpart of RenderManager's fan-out and ImageBuilder's gather (manager.rs:156-162, 316-324) --
+ * and is compared HERE, with memcmp, against the whole frame from flux_render_rows and against the one-call
+ * flux_render_frame_multi; a second flux_multi on the same devices must find the communicators cached.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -42,8 +48,8 @@ static flux_shape sphere(double x, double y, double z, double radius, int invert
 }
 
 int main(int argc, char **argv) {
-    if (argc != 7) {
-        fprintf(stderr, "usage: %s out.bin width height sample_root seed rows_per_unit\n", argv[0]);
+    if (argc != 7 && !(argc == 10 && strcmp(argv[7], "multi") == 0)) {
+        fprintf(stderr, "usage: %s out.bin width height sample_root seed rows_per_unit [multi G shard]\n", argv[0]);
         return 2;
     }
     const uint64_t width = strtoull(argv[2], NULL, 10), height = strtoull(argv[3], NULL, 10);
@@ -113,6 +119,90 @@ int main(int argc, char **argv) {
     if (flux_render_rows(ctx, height, height, frame) != FLUX_E_INVALID || strlen(flux_last_error()) == 0) {
         fprintf(stderr, "out-of-range work unit was not rejected\n");
         return 1;
+    }
+    if (argc == 10) {
+        const uint64_t G = strtoull(argv[8], NULL, 10);
+        const int shard = atoi(argv[9]);
+        const size_t doubles = (size_t)(width * height * 3);
+        int devices[64];
+        double *whole = (double *)malloc(doubles * sizeof(double)), *multi = (double *)malloc(doubles * sizeof(double));
+        double *once = (double *)malloc(doubles * sizeof(double));
+        if (!whole || !multi || !once || G < 1 || G > 64) return 1;
+        for (uint64_t g = 0; g < G; g++) devices[g] = (int)g;
+        if (flux_render_rows(ctx, 0, height - 1, whole) != FLUX_OK) {   /* every row, also the one job.rs:74 never issues */
+            fprintf(stderr, "flux_render_rows: %s\n", flux_last_error());
+            return 1;
+        }
+        flux_multi *m = NULL, *m2 = NULL;
+        if (flux_multi_create(&sd, &cfg, seed, devices, G, shard, &m) != FLUX_OK) {
+            fprintf(stderr, "flux_multi_create: %s\n", flux_last_error());
+            return 1;
+        }
+        for (int frame_no = 0; frame_no < 2; frame_no++) {   /* twice: the second frame re-uses every buffer */
+            memset(multi, 0xff, doubles * sizeof(double));
+            if (flux_multi_render_frame(m, multi) != FLUX_OK) {
+                fprintf(stderr, "flux_multi_render_frame: %s\n", flux_last_error());
+                return 1;
+            }
+            if (memcmp(multi, whole, doubles * sizeof(double)) != 0) {
+                fprintf(stderr, "frame %d of flux_multi_render_frame differs from flux_render_rows\n", frame_no);
+                return 1;
+            }
+        }
+        uint64_t info[FLUX_MULTI_INFO_WORDS];
+        double ms[FLUX_MULTI_TIMING_WORDS];
+        if (flux_multi_info(m, info) != FLUX_OK || flux_multi_timing(m, ms) != FLUX_OK) return 1;
+        printf("multi: devices %llu shard %llu rccl %llu share_doubles %llu ctx_bytes %llu buffer_bytes %llu cached %llu\n",
+               (unsigned long long)info[0], (unsigned long long)info[1], (unsigned long long)info[2], (unsigned long long)info[3],
+               (unsigned long long)info[4], (unsigned long long)info[5], (unsigned long long)info[6]);
+        printf("multi_ms: create %.3f ctx %.3f comm %.3f frame %.3f kernel %.3f gather %.3f assemble %.3f d2h %.3f\n", ms[0], ms[1], ms[2],
+               ms[3], ms[4], ms[5], ms[6], ms[7]);
+        if (info[0] != G || info[2] == 0 || info[6] != 0) {
+            fprintf(stderr, "flux_multi_info: unexpected contents\n");
+            return 1;
+        }
+        flux_ctx *rank0 = NULL;
+        int64_t plan[FLUX_PLAN_WORDS];
+        if (flux_multi_ctx(m, 0, &rank0) != FLUX_OK || !rank0 || flux_multi_ctx(m, G, &rank0) != FLUX_E_INVALID) return 1;
+        if (flux_multi_ctx(m, 0, &rank0) != FLUX_OK || flux_ctx_launch_plan(rank0, info[1] == FLUX_SHARD_ROWS ? (height + G - 1) / G : 0,
+                                                                           info[1] == FLUX_SHARD_SETS ? (width + G - 1) / G : 0, plan) != FLUX_OK) {
+            fprintf(stderr, "launch plan of rank 0: %s\n", flux_last_error());
+            return 1;
+        }
+        printf("multi_plan: kernel %lld block %lld blocks %lld\n", (long long)plan[0], (long long)plan[1], (long long)plan[2]);
+        /* a second job on the same devices (flux/src/main.rs:247,304,313 schedules job after job): communicators from the cache */
+        if (flux_multi_create(&sd, &cfg, seed, devices, G, shard, &m2) != FLUX_OK || flux_multi_info(m2, info) != FLUX_OK || info[6] != 1) {
+            fprintf(stderr, "second flux_multi_create: %s (cached %llu)\n", flux_last_error(), (unsigned long long)info[6]);
+            return 1;
+        }
+        const void *d_frame = NULL;
+        if (flux_multi_render_frame_device(m2, &d_frame) != FLUX_OK || !d_frame) {
+            fprintf(stderr, "flux_multi_render_frame_device: %s\n", flux_last_error());
+            return 1;
+        }
+        flux_multi_destroy(m2);
+        flux_multi_destroy(m);
+        /* the one-call form: a job's whole life */
+        if (flux_render_frame_multi(&sd, &cfg, seed, NULL, G, shard, once) != FLUX_OK) {
+            fprintf(stderr, "flux_render_frame_multi: %s\n", flux_last_error());
+            return 1;
+        }
+        if (memcmp(once, whole, doubles * sizeof(double)) != 0) {
+            fprintf(stderr, "flux_render_frame_multi differs from flux_render_rows\n");
+            return 1;
+        }
+        /* error behaviour: codes + messages, never an abort */
+        devices[0] = 0;
+        devices[1] = 0;
+        if (flux_multi_create(&sd, &cfg, seed, devices, 2, shard, &m) != FLUX_E_INVALID || strlen(flux_last_error()) == 0) return 1;
+        if (flux_multi_release_comms() != 1) {
+            fprintf(stderr, "expected ONE cached device list\n");
+            return 1;
+        }
+        memcpy(frame, multi, doubles * sizeof(double));
+        free(whole);
+        free(multi);
+        free(once);
     }
     flux_ctx_destroy(ctx);
     FILE *f = fopen(argv[1], "wb");

@@ -97,6 +97,8 @@ C_TO_RUST = {
     "int64_t *": "*mut i64", "int32_t *": "*mut i32", "const uint8_t *": "*const u8", "void *": "*mut c_void",
     "flux_ctx *": "*mut FluxCtx", "flux_ctx **": "*mut *mut FluxCtx", "const flux_scene_desc *": "*const FluxSceneDesc",
     "const flux_job_cfg *": "*const FluxJobCfg", "flux_work_unit *": "*mut FluxWorkUnit",
+    "flux_multi *": "*mut FluxMulti", "flux_multi **": "*mut *mut FluxMulti", "const int *": "*const c_int",
+    "const void **": "*mut *const c_void",
 }
 
 
@@ -138,7 +140,7 @@ def _rust_prototypes():
 
 def test_integration_md_rust_block_binds_every_function():
     c, rust = _c_prototypes(), _rust_prototypes()
-    assert len(c) >= 26, sorted(c)                    # the parser saw the whole header
+    assert len(c) >= 38, sorted(c)                    # the parser saw the whole header
     assert set(rust) == set(c), (sorted(set(c) - set(rust)), sorted(set(rust) - set(c)))
     for name, (ret, args) in c.items():
         r_ret, r_args = rust[name]

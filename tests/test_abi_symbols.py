@@ -27,9 +27,9 @@ def test_header_functions_are_exported(flux):
 
 def test_version_and_error_surface(flux):
     lib = flux._lib.lib
-    assert lib.flux_abi_version() == 2 == flux._lib.ABI_VERSION
+    assert lib.flux_abi_version() == 3 == flux._lib.ABI_VERSION
     header = open(os.path.join(ROOT, "include", "flux_abi.h")).read()
-    assert re.search(r"#define\s+FLUX_ABI_VERSION\s+2\b", header)
+    assert re.search(r"#define\s+FLUX_ABI_VERSION\s+3\b", header)
     # introspection calls check their arguments without a device
     assert lib.flux_ctx_bvh_info(None, None, 16) == flux._lib.E_INVALID
     assert lib.flux_ctx_launch_plan(None, 0, 0, None) == flux._lib.E_INVALID
@@ -39,6 +39,14 @@ def test_version_and_error_surface(flux):
     lib.flux_ctx_destroy(None)  # no-op, like dropping nothing
     assert lib.flux_ctx_device_bytes(None) == 0
     assert lib.flux_ctx_last_kernel_ms(None) < 0
+    # the multi-GPU entry points (ABI version 3) check their arguments before they look for a device or for RCCL
+    assert lib.flux_multi_create(None, None, 0, None, 0, 0, None) == flux._lib.E_INVALID
+    assert lib.flux_multi_render_frame(None, None) == flux._lib.E_INVALID
+    assert lib.flux_multi_info(None, None) == flux._lib.E_INVALID
+    assert lib.flux_render_frame_multi(None, None, 0, None, 0, 0, None) == flux._lib.E_INVALID
+    lib.flux_multi_destroy(None)
+    assert lib.flux_multi_release_comms() == 0  # nothing cached: no communicator was ever made
+    assert lib.flux_ctx_create_timing(None, None) == flux._lib.E_INVALID
 
 
 def test_struct_layout_matches_header(flux):

@@ -129,3 +129,26 @@ def test_node_protocol_end_to_end(binaries, tmp_path):
     assert a.shape == (600, 800, 3) and np.array_equal(a, b)
     out = open(tmp_path / "node.log").read()
     assert "Got job" in out and "Got done message" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("root,split", [(8, "sets"), (8, "rows"), (3, "sets")])
+def test_cli_split_frame_equals_split_units(binaries, tmp_path, root, split):
+    """`flux --split sets|rows` (the compiled host's multi-GPU path: ONE MultiGpuWorker over flux_multi_*, i.e. per-device contexts,
+    one launch per device, ncclCommInitAll + one ncclAllGather from RCCL's C API, reassembly on the device) writes the same PPM,
+    byte for byte, as `--split units` (one GpuWorker per device pulling WorkUnits, the reference's scheme: manager.rs:100,156-162).
+    One device here; root 3 is below 64 spp, where `sets` falls back to row tiles.  -R 7: 600 = 85 * 7 + 5 (every row issued)."""
+    scene = os.path.join(SCENES, "demo2.yml")
+    outs = {}
+    for mode in ("units", split):
+        d = tmp_path / mode
+        d.mkdir()
+        r = subprocess.run([binaries[0], scene, "-r", str(root), "-R", "7", "--seed", "9", "--gpus", "1", "--split", mode, "--outdir", str(d)],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr + r.stdout
+        if mode != "units":
+            assert "one RCCL all-gather" in r.stdout and "multi-GPU frame: create" in r.stdout, r.stdout
+        outs[mode] = open(d / "demo2.ppm", "rb").read()
+    assert outs[split] == outs["units"]
+    r = subprocess.run([binaries[0], scene, "--split", "sets", "-L", "-n", "127.0.0.1:1"], capture_output=True, text=True)
+    assert r.returncode == 2 and "--split units" in r.stderr
