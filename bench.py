@@ -183,6 +183,30 @@ def rccl_probe(frame_bytes):
     return rep
 
 
+def multi_abi_probe(flux_amd, sd, cfg, a, frame):
+    """N = 1 only, after the timed region: the SAME frame through the C ABI's multi-GPU entry (flux_multi_*: per-device context,
+    one launch, ncclCommInitAll + ncclAllGather from RCCL's C API, reassembly kernel) on this one device -- what a compiled
+    embedder (the reference's Rust host, the C++ `flux --split sets`) runs instead of torch.distributed.  Reports its own timing
+    words and whether the frame equals the timed one bit for bit.  Never raises."""
+    try:
+        import numpy as np
+        t0 = time.perf_counter()
+        with flux_amd.MultiRenderer(sd, cfg, seed=a.seed, devices=[0]) as m:
+            m.set_kernel(a.kernel)
+            m.set_math(flux_amd.MATH_FAST if a.math == "fast" else flux_amd.MATH_STRICT)
+            t_create = time.perf_counter() - t0
+            m.render_frame()                      # warm-up
+            got = m.render_frame()
+            rep = {"ran": True, **{k: round(v, 3) for k, v in m.timing().items()}, **m.info(),
+                   "python_create_wall_ms": round(t_create * 1e3, 2),
+                   "frame_equals_timed_frame": bool(np.array_equal(got, frame.cpu().numpy())),
+                   "note": "flux_multi_create / flux_multi_render_frame on devices [0]: RCCL through the C ABI at G = 1 (says nothing about xGMI)"}
+        flux_amd.release_comms()
+        return rep
+    except Exception as ex:  # noqa: BLE001 -- a probe: report, never fail the bench
+        return {"ran": False, "error": f"{type(ex).__name__}: {ex}"[:300]}
+
+
 def self_launch(n_gpus):
     """`python bench.py --gpus N` from a bare shell: start N fresh ranks under torch.distributed.run and return
     their exit code.  Runs BEFORE torch / flux_amd are imported, so this process never touches the GPU (a process
@@ -310,11 +334,24 @@ def main():
     # locality, flux_amd/dist.py SetSharder) -- the same code path at every N; `--shard rows` forces row tiles.
     # A set-sharded rank builds and holds only its own sets' tables (flux_ctx_create_sets).
     use_sets = a.shard == "sets" or (a.shard == "auto" and n * n >= 64)
+    share = (rank, world) if use_sets else None
+    # The FIRST context of the process: its wall time contains the HIP runtime's lazy initialisation (device context, copy engine,
+    # compute queue, code object: scripts/micro/cold_start.hip) -- process start-up, which the reference's job timer never sees.
     t0 = time.perf_counter()
-    r = flux_amd.Renderer(sd, cfg, seed=a.seed, device=local_rank, set_share=(rank, world) if use_sets else None)
+    r = flux_amd.Renderer(sd, cfg, seed=a.seed, device=local_rank, set_share=share)
+    torch.cuda.synchronize()
+    t_create_cold = time.perf_counter() - t0
+    create_cold = r.create_timing()
+    # ... and a SECOND, identical context beside it: what Scene::from_data + Camera::new (workers.rs:46-54) cost a running worker,
+    # i.e. what the reference's timer (manager.rs:145 -> 170) spans for every job.  Created, timed, destroyed.
+    t0 = time.perf_counter()
+    r2 = flux_amd.Renderer(sd, cfg, seed=a.seed, device=local_rank, set_share=share)
     torch.cuda.synchronize()
     t_create = time.perf_counter() - t0
-    phase(rank, world, f"ctx created ({t_create * 1e3:.0f} ms)")
+    create_warm = r2.create_timing()
+    r2.close()
+    del r2
+    phase(rank, world, f"ctx created ({t_create_cold * 1e3:.0f} ms the process's first, {t_create * 1e3:.1f} ms a second one)")
     r.set_kernel(a.kernel)
     r.set_math(flux_amd.MATH_FAST if a.math == "fast" else flux_amd.MATH_STRICT)
     if use_sets:
@@ -369,6 +406,13 @@ def main():
     spread = {name: {"min": round(float(allt[:, j].min()), 3), "mean": round(float(allt[:, j].mean()), 3),
                      "max": round(float(allt[:, j].max()), 3)}
               for j, name in ((1, "render"), (2, "all_gather"), (3, "reassembly"), (4, "launch_overhead_ms"))}
+
+    # the frame's way to the host (the reference-equivalent span ends with the image in host memory, manager.rs:316-324): one
+    # device-to-host copy of the assembled frame into pageable memory, timed on rank 0 (untimed extra)
+    t0 = time.perf_counter()
+    frame_host = frame.cpu()
+    t_d2h = time.perf_counter() - t0
+    del frame_host
 
     # what HBM delivers on THIS device ("report against both" the 8 TB/s spec and a measured copy): a 1 GiB
     # device-to-device copy, read + write bytes, best of 5 (untimed extra)
@@ -456,7 +500,9 @@ def main():
         valu_insts = prof["valu_insts_per_launch"] * scale if prof and prof.get("valu_insts_per_launch") else None
         # VALU issue ceiling: 256 CU x 4 SIMD wave-instructions per (mean cycles per instruction of THIS kernel's mix) at the
         # nominal 2.4 GHz -- 614 G/s at 4 cycles each, 632 G/s for the split kernel's measured mix
-        issue_cycles = ISSUE_CYCLES_PER_INST.get(kernel_name, 4.1)
+        # ... from the committed profile's own class counters when it has them (scripts/valu_classes.sh + summarize_profile.py), else
+        # the round-5 figures above
+        issue_cycles = (prof or {}).get("issue_cycles_per_inst") or ISSUE_CYCLES_PER_INST.get(kernel_name, 4.1)
         issue_peak = 256 * 4 * NOMINAL_CLOCK_HZ / issue_cycles
         out = {
             "metric": (f"Msamples/sec on {a.scene}.yml (fixed spp)" if not a.scene.startswith("hf:") else
@@ -521,6 +567,9 @@ def main():
                          "fp64_issue_frac": (None if valu_insts is None else
                                              round(valu_insts / (kernel_ms_max * 1e-3) / issue_peak, 4)),
                          "issue_cycles_per_inst": issue_cycles,
+                         "issue_cycles_from": ("the committed profile's dynamic class counters" if (prof or {}).get("issue_cycles_per_inst")
+                                               else "round 5's class mix (bench.py ISSUE_CYCLES_PER_INST)"),
+                         "valu_classes_per_64_samples": (prof or {}).get("valu_classes_per_64_samples"),
                          "issue_note": "fp64_issue_frac = VALU instructions/s x mean cycles per instruction of this kernel's class mix "
                                        "(profiles/r05_valu_issue.json) / (1024 SIMDs x 2.4 GHz; the render kernels run at 2.38 GHz, "
                                        "scripts/kernel_clock.sh): the fraction of cycles in which the VALU issues.  valu_busy_frac (SQ_ACTIVE_INST_VALU x 4 "
@@ -541,11 +590,40 @@ def main():
                                  "L2s (`traffic`: what reached the memory side).  The analytic kernels are VALU-issue bound "
                                  "(valu_busy_frac); lanes_active_frac = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU); "
                                  "useful_valu_frac = model lane-operations (DESIGN.md section 4) / issued lane slots"},
-            "ctx_create_ms": round(t_create * 1e3, 1),
-            "reference_equivalent_s": round(t_create + elapsed_max / a.steps, 4),
+            # the job as the reference times it (manager.rs:145 -> 170: Scene::from_data + Camera::new incl. MasterSampleSets::new,
+            # workers.rs:46-54, then the render, then the rows in host memory): a running worker's context creation (the SECOND
+            # context of this process) + one frame + the frame's copy to the host.  `_cold_s`: the same with the process's FIRST
+            # context, whose creation also pays the HIP runtime's one-time initialisation.
+            "ctx_create_ms": round(t_create * 1e3, 2),
+            "ctx_create_breakdown_ms": {k: round(v, 3) for k, v in create_warm.items()},
+            "ctx_create_cold_ms": round(t_create_cold * 1e3, 1),
+            "ctx_create_cold_breakdown_ms": {k: round(v, 3) for k, v in create_cold.items()},
+            "ctx_create_note": "flux_ctx_create_timing: host = validation + scene records (+ BVH build), runtime = HIP device initialisation, "
+                               "alloc / upload / tables (MasterSampleSets::new on the device) / free / other; cold = the process's first "
+                               "context (runtime + first-copy / first-launch set-up land in it), ctx_create_ms = a second context",
+            "frame_d2h_ms": round(t_d2h * 1e3, 3),
+            "reference_equivalent_s": round(t_create + elapsed_max / a.steps + t_d2h, 4),
+            "reference_equivalent_cold_s": round(t_create_cold + elapsed_max / a.steps + t_d2h, 4),
+            "build_id": (flux_amd._lib.lib.flux_build_id() or b"").decode(),
         }
+        out["reference_equivalent_msamples_s"] = round(samples / out["reference_equivalent_s"] / 1e6, 1)
+        if out["vs_baseline"] is not None:
+            # the published 1479.9 s spans table construction + render + gather: compared on the same span
+            out["vs_baseline"] = round(samples / out["reference_equivalent_s"] / 1e6 / PUBLISHED_MSAMPLES_S, 1)
+            out["vs_baseline_span"] = ("reference-equivalent (context creation of a running worker + one frame + the frame's copy to "
+                                       "the host) against README.md's 1479.9 s, which spans the same steps; value / 5.314 would be "
+                                       f"{round(samples * a.steps / elapsed_max / 1e6 / PUBLISHED_MSAMPLES_S, 1)}")
+        prof_kernels = (prof or {}).get("build_id", "")
+        out["roofline"]["profile_build_id"] = prof_kernels or None
+        out["roofline"]["profile_head"] = (prof or {}).get("git_head")
+        same = bool(prof_kernels) and prof_kernels.split("kernels:")[-1] == out["build_id"].split("kernels:")[-1]
+        out["roofline"]["profile_matches_build"] = same if prof else None
+        if prof and not same:
+            out["roofline"]["profile_warning"] = ("the committed PMC profile was taken from another build of the kernels: the "
+                                                  "from_committed_profile fields describe THAT binary")
         if world == 1 and not a.no_rccl_probe:
             out["rccl_probe"] = rccl_probe(int(sh.local.numel() * 8))
+            out["multi_abi"] = multi_abi_probe(flux_amd, sd, cfg, a, frame)
         if world == 1 and not a.no_cpu_baseline:
             if a.scene.startswith("hf:"):
                 # the CPU checker scans every triangle per ray (it DEFINES what the BVH must reproduce): ~5 ms per ray on

@@ -78,6 +78,8 @@ SYMBOLS = {
     "flux_abi_version": (C.c_uint32, []),
     "flux_last_error": (C.c_char_p, []),
     "flux_device_count": (C.c_int, []),
+    "flux_build_id": (C.c_char_p, []),
+    "flux_device_warmup": (C.c_int, [C.c_int]),
     "flux_ctx_create": (C.c_int, [C.POINTER(FluxSceneDesc), C.POINTER(FluxJobCfg), C.c_uint64, C.c_int,
                                   C.POINTER(_P)]),
     "flux_ctx_create_sets": (C.c_int, [C.POINTER(FluxSceneDesc), C.POINTER(FluxJobCfg), C.c_uint64, C.c_int, C.c_uint64,
@@ -142,7 +144,7 @@ def _load():
     _one_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            f"{LIB_PATH} not found: build it with `python -m flux_amd.build` "
+            f"{LIB_PATH} not found: build it with `python flux_amd/build.py` "
             "(the renderer has no CPU fallback)")
     lib = C.CDLL(LIB_PATH)
     # the version FIRST: a stale library lacks newer symbols, and the loop below would die on the first of them with a bare
@@ -155,7 +157,7 @@ def _load():
         have = 1  # version 1 had no such symbol
     if have != ABI_VERSION:
         raise ImportError(f"{LIB_PATH} speaks ABI version {have}, this binding {ABI_VERSION}: rebuild it "
-                          "(python -m flux_amd.build --force)")
+                          "(python flux_amd/build.py --force)")
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing
         fn.restype = res

@@ -40,11 +40,36 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+# the sources that become DEVICE code (the render / table kernels): their hash is the `kernels:` half of flux_build_id()
+KERNEL_FILES = ["render.hip", "render_body.inc", "tables.hip", "flux_device.h", "flux_bvh.h", "flux_math.h", "flux_math_coeffs.h",
+                "flux_rng.h", "flux_tables.h"]
+
+
+def build_id(extra_flags=()):
+    """"lib:<16 hex> kernels:<16 hex>": sha256 over (flags, every source) and over (flags, the device-code sources)."""
+    import hashlib
+
+    def digest(names):
+        h = hashlib.sha256()
+        h.update(" ".join(HIP_FLAGS + list(extra_flags)).encode())
+        for n in names:
+            path = os.path.join(ROOT, "include", n) if n == "flux_abi.h" else os.path.join(CSRC, n)
+            h.update(n.encode() + b"\0")
+            with open(path, "rb") as f:
+                h.update(f.read())
+        return h.hexdigest()[:16]
+    return f"lib:{digest(sorted(set(HIP_SOURCES + HIP_HEADERS + ['flux_abi.h'])))} kernels:{digest(KERNEL_FILES)}"
+
+
+def _id_flag(extra_flags=()):
+    return "-DFLUX_BUILD_ID=\"" + build_id(extra_flags) + "\""
+
+
 def build_variant(out_path, extra_flags, verbose=False):
     """Experiment builds (scripts/sweep_variants.py): same sources, extra -D/-f flags."""
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     flags = [f for f in HIP_FLAGS if not (f == "-ffp-contract=off" and any(x.startswith("-ffp-contract") for x in extra_flags))]
-    cmd = [_hipcc()] + flags + list(extra_flags) + ["-o", out_path] + srcs
+    cmd = [_hipcc()] + flags + list(extra_flags) + [_id_flag(extra_flags), "-o", out_path] + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)
@@ -56,7 +81,7 @@ def build_hip(force=False, verbose=False):
     deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(ROOT, "include", "flux_abi.h")]
     if not force and not _newer(HIP_LIB, deps):
         return HIP_LIB
-    cmd = [_hipcc()] + HIP_FLAGS + ["-o", HIP_LIB] + srcs
+    cmd = [_hipcc()] + HIP_FLAGS + [_id_flag(), "-o", HIP_LIB] + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -231,6 +231,9 @@ int GpuWorker::failures() { return worker_failures_.load(); }
 void GpuWorker::note_failure() { worker_failures_.fetch_add(1); }
 
 void GpuWorker::run() {
+    // the worker's one-time set-up, before any job (LocalWorker::new builds its rayon pool here, workers.rs:27-38): the HIP runtime's
+    // lazy initialisation on this device, so that a job's timer (manager.rs:145) sees the context's work and not the process's
+    (void)flux_device_warmup(device_);
     // 'main: while let Ok(Some((job, recv_unit, send_result, wg))) = r.recv()   (workers.rs:43)
     for (;;) {
         auto msg = sender_->recv();
@@ -317,6 +320,11 @@ std::vector<double> MultiGpuWorker::last_timing() const {
 }
 
 void MultiGpuWorker::run() {
+    {   // one-time set-up per device, concurrently (see GpuWorker::run)
+        std::vector<std::thread> th;
+        for (int d : devices_) th.emplace_back([d] { (void)flux_device_warmup(d); });
+        for (std::thread &t : th) t.join();
+    }
     for (;;) {
         auto msg = sender_->recv();
         if (!msg || !*msg) break;

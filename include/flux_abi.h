@@ -137,6 +137,17 @@ const char *flux_last_error(void);
 /* Number of usable devices (0 when no GPU is visible; never fails). */
 int flux_device_count(void);
 
+/* Identity of the library's sources, fixed at build time (flux_amd/build.py): "lib:<16 hex> kernels:<16 hex>" -- hashes of all
+ * sources + flags, and of the device-code sources alone (render.hip, render_body.inc, tables.hip and the headers they include).
+ * A profile summary under profiles/ records the id of the binary it was taken from; bench.py compares. */
+const char *flux_build_id(void);
+
+/* Brings the HIP runtime up on `device` -- device context, the first copy, the first kernel launch of this library's code object,
+ * a stream -- so that the first flux_ctx_create on it costs what every later one does (7 ms for demo2 at 16384 spp instead of 30-130).
+ * The reference's counterpart is LocalWorker::new building its rayon pool when the worker is made (workers.rs:27-38), before any
+ * job's timer runs (manager.rs:145).  Optional; idempotent; safe from any thread. */
+int flux_device_warmup(int device);
+
 /* Replaces Scene::from_data (scene.rs:128-154) + Camera::new (trace.rs:26-42)
  * incl. MasterSampleSets::new (sampling.rs:13-33): copies the scene, uploads
  * it to HBM and generates the S = image_width sample sets of pixel / lens-disc

@@ -79,8 +79,9 @@ if calib:
     out["fetch_calibration"] = {k: {"fetch_size_bytes": v, "true_bytes": float(1 << 30),
                                     "true_over_reported": [float(1 << 30) / x if x else None for x in v]}
                                 for k, v in calib.items()}
-workload = scene = kname = spl = None
+workload = scene = kname = spl = build = None
 for b in bench.values():
+    build = b.get("build_id", build)
     workload = b.get("config", {}).get("workload", workload)
     scene = b.get("config", {}).get("scene", scene)
     kname = b.get("roofline", {}).get("kernel", kname)
@@ -89,6 +90,35 @@ out["workload"] = workload
 out["scene"] = scene                 # bench.py matches a profile by scene + kernel and scales the counters per sample
 out["kernel"] = kname
 out["samples_per_launch"] = spl
+# which binary this is a profile of: the library's own id (flux_build_id, printed by bench.py) and the checkout it was summarised in
+out["build_id"] = build
+try:
+    import subprocess
+    out["git_head"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    out["git_dirty"] = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "flux_amd/csrc", "include"], capture_output=True,
+                                           text=True).stdout.strip())
+except Exception:
+    out["git_head"] = None
+# dynamic VALU instruction classes of the same build (scripts/valu_classes.sh <tag> ...), when that pass was run: the mean issue
+# cost of one VALU instruction follows from them and the per-class costs measured by scripts/micro/valu_issue.hip
+# (profiles/r05_valu_issue.json): f64 add / mul / fma 4.13 cycles, f64 transcendental seeds 16.1, f32 fma (the packed filter) 4.13,
+# plain f32 add / mul 2.45, conversions 4.67, int32 3.3, int64 4.13, and the instructions no class counts (moves, compares, selects,
+# lane operations) 3.43 -- their static mix in round 5's listing (170 moves x 2.45, 100 compares x 4.75, 90 selects x 3.3, 42 others x 4.5)
+vc = os.path.join(ROOT, "gpurun_out", f"valu_{tag}", "summary.json")
+if os.path.exists(vc):
+    per = json.load(open(vc))["per_64_samples"]
+    cost = {"ADD_F64": 4.13, "MUL_F64": 4.13, "FMA_F64": 4.13, "TRANS_F64": 16.1, "ADD_F32": 2.45, "MUL_F32": 2.45, "FMA_F32": 4.13,
+            "TRANS_F32": 4.13, "CVT": 4.67, "INT32": 3.3, "INT64": 4.13}
+    tot = per["SQ_INSTS_VALU"]
+    cl = {c: per.get("SQ_INSTS_VALU_" + c, 0.0) for c in cost}
+    other = tot - sum(cl.values())
+    cycles = sum(cl[c] * cost[c] for c in cost) + other * 3.43
+    out["valu_classes_per_64_samples"] = {**{c.lower(): round(v, 2) for c, v in cl.items()}, "other": round(other, 2), "total": round(tot, 2),
+                                          "salu": round(per.get("SQ_INSTS_SALU", 0.0), 2), "smem": round(per.get("SQ_INSTS_SMEM", 0.0), 2),
+                                          "lds": round(per.get("SQ_INSTS_LDS", 0.0), 2), "vmem_rd": round(per.get("SQ_INSTS_VMEM_RD", 0.0), 2),
+                                          "branch": round(per.get("SQ_INSTS_BRANCH", 0.0), 2)}
+    out["issue_cycles_per_inst"] = round(cycles / tot, 3)
+    out["f64_inst_frac"] = round((cl["ADD_F64"] + cl["MUL_F64"] + cl["FMA_F64"] + cl["TRANS_F64"]) / tot, 4)
 main = None
 for name, cs in counters.items():
     k = {c: sum(v) / len(v) for c, v in cs.items()}
