@@ -188,6 +188,11 @@ def multi_abi_probe(flux_amd, sd, cfg, a, frame):
     one launch, ncclCommInitAll + ncclAllGather from RCCL's C API, reassembly kernel) on this one device -- what a compiled
     embedder (the reference's Rust host, the C++ `flux --split sets`) runs instead of torch.distributed.  Reports its own timing
     words and whether the frame equals the timed one bit for bit.  Never raises."""
+    # RCCL prints a version banner to STDOUT when its first communicator comes up; stdout carries the ONE JSON line, so file
+    # descriptor 1 points at stderr while the probe runs
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
     try:
         import numpy as np
         t0 = time.perf_counter()
@@ -205,6 +210,10 @@ def multi_abi_probe(flux_amd, sd, cfg, a, frame):
         return rep
     except Exception as ex:  # noqa: BLE001 -- a probe: report, never fail the bench
         return {"ran": False, "error": f"{type(ex).__name__}: {ex}"[:300]}
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def self_launch(n_gpus):

@@ -309,7 +309,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     // scalar operands instead of through every lane's candidate list (render_body.inc scan_shapes_fast): up to two,
     // given a filter record that never passes (c = 3e38: "entirely behind the origin" or dq < 0)
     int n_uni = 0, uni_idx[2] = {0, 0};
-    if (FLUX_FILTER32 && filter32_ok)
+    if (filter32_ok)
         for (size_t k = 0; k < fsph.size() && n_uni < FLUX_UNI_SPHERES; k++)
             if (frec_s[k].inv_rad < 0.0) uni_idx[n_uni++] = (int)k;
     for (size_t k = 0; k < fsph.size(); k++) {
@@ -410,14 +410,10 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         delete c;
         return code;
     }
-#if FLUX_BVH4_ARENA
     // round 5: nodes and leaf records in ONE arena of 64-B units, a node's children contiguous (flux_bvh.h DevNode4A); an
     // arena beyond the 26-bit unit index comes back empty and the mesh is walked by the binary tree's kernel
     std::vector<flux::DevNode4A> arena;
     flux::build_wide_arena(nodes, nodesq, tris, arena, c->bvh);
-#else
-    flux::build_wide(nodes, nodesq, tris, nodes4, leafrecs, c->bvh);
-#endif
     if (nodes4.size() * sizeof(flux::DevNode4Q) >= (1ull << 32) || leafrecs.size() * sizeof(flux::DevLeafRec) >= (1ull << 32) ||
         leafrecs.size() >= (1ull << 28)) {
         int code = fail(FLUX_E_INVALID, "mesh too large for the traversal kernel's 32-bit record offsets");
@@ -499,7 +495,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     alloc((void **)&c->d_pix, pix_bytes);
     alloc((void **)&c->d_disc, pix_bytes);
     alloc((void **)&c->d_hemi, hemi_bytes);
-    if (FLUX_GLOSS_TABLE) alloc((void **)&c->d_gloss, pix_bytes * 2);
+    alloc((void **)&c->d_gloss, pix_bytes * 2);
     alloc((void **)&c->d_setrows, own * sizeof(flux::DevSetRows));
     alloc((void **)&c->d_rowperm, perm_bytes);
     alloc((void **)&c->d_invperm, perm_bytes);
@@ -511,18 +507,10 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         if (e == hipSuccess) e = hipMemcpy(c->d_nodes, nodes.data(), nodes.size() * sizeof(flux::DevNode), hipMemcpyHostToDevice);
         alloc((void **)&c->d_nodesq, nodesq.size() * sizeof(flux::DevNodeQ));
         if (e == hipSuccess) e = hipMemcpy(c->d_nodesq, nodesq.data(), nodesq.size() * sizeof(flux::DevNodeQ), hipMemcpyHostToDevice);
-#if FLUX_BVH4_ARENA
         if (!arena.empty()) {
             alloc((void **)&c->d_nodes4, arena.size() * sizeof(flux::DevNode4A));
             if (e == hipSuccess) e = hipMemcpy(c->d_nodes4, arena.data(), arena.size() * sizeof(flux::DevNode4A), hipMemcpyHostToDevice);
         }
-#else
-        alloc((void **)&c->d_nodes4, nodes4.size() * sizeof(flux::DevNode4Q));
-        if (e == hipSuccess) e = hipMemcpy(c->d_nodes4, nodes4.data(), nodes4.size() * sizeof(flux::DevNode4Q), hipMemcpyHostToDevice);
-        alloc((void **)&c->d_leaves, (leafrecs.size() + 1) * sizeof(flux::DevLeafRec));
-        if (e == hipSuccess && !leafrecs.empty())
-            e = hipMemcpy(c->d_leaves, leafrecs.data(), leafrecs.size() * sizeof(flux::DevLeafRec), hipMemcpyHostToDevice);
-#endif
     }
     if (e == hipSuccess) e = hipMemcpy(c->d_shapes, shapes.data(), shapes.size() * sizeof(flux::DevShape), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->d_mats, mats.data(), mats.size() * sizeof(flux::DevMaterial), hipMemcpyHostToDevice);
@@ -537,7 +525,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     double tab_ms[3] = {0, 0, 0};
     if (e == hipSuccess)
         e = flux::generate_tables(seed, c->S, c->sets, c->D, c->n, c->H, c->d_pix, c->d_disc, c->d_hemi, c->d_rowperm, c->d_invperm, nullptr, tab_ms);
-    if (e == hipSuccess && FLUX_GLOSS_TABLE) {
+    if (e == hipSuccess) {
         e = flux::generate_gloss_table(c->d_pix, (size_t)c->sets.count * c->N, c->d_gloss, nullptr);
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     }
@@ -593,7 +581,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.fsph = reinterpret_cast<const flux::DevScanSphere *>(c->d_fscene);
     rp.fpln = reinterpret_cast<const flux::DevScanPlane *>(c->d_fscene + fs_sph_bytes);
     rp.frec = reinterpret_cast<const flux::DevHitRec *>(c->d_fscene + fs_sph_bytes + fs_pln_bytes);
-    rp.fsph32 = (FLUX_FILTER32 && filter32_ok)
+    rp.fsph32 = filter32_ok
                     ? reinterpret_cast<const flux::DevScanSphere32 *>(c->d_fscene + fs_sph_bytes + fs_pln_bytes + fs_rec_bytes)
                     : nullptr;
     rp.sshapes = reinterpret_cast<const flux::DevShape *>(c->d_fscene + fs_ss_off);
@@ -615,7 +603,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.uni_idx[0] = uni_idx[0];
     rp.uni_idx[1] = uni_idx[1];
     rp.unit_dirs = rp.glossy_long ? 0 : 1;
-    rp.self_skip = (FLUX_SELF_SKIP && !rp.glossy_long) ? 1 : 0;
+    rp.self_skip = rp.glossy_long ? 0 : 1;
     {   // the environment shortcut (flux_device.h env_short): exactly one `invert` sphere, Emissive, of ordinary size
         int inverted = 0;
         for (const flux::DevHitRec &hr : frec_s)
@@ -623,7 +611,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         rp.env_short = 0;
         rp.pad_env = 0;
         rp.env_radius = 0.0;
-        if (FLUX_ENV_SHORT && n_uni == 1 && inverted == 1 && frec_s[uni_idx[0]].mat_kind == flux::kMatEmissive) {
+        if (n_uni == 1 && inverted == 1 && frec_s[uni_idx[0]].mat_kind == flux::kMatEmissive) {
             const double rad = std::sqrt(fsph[uni_idx[0]].rr);
             if (rad > 1e-3 && rad < 1e6) {
                 rp.env_short = 1;
@@ -883,7 +871,7 @@ int flux_render_sets_device(flux_ctx *ctx, uint64_t first_set, uint64_t set_stri
     if (first_set >= ctx->S || first_set + (num_sets - 1) * set_stride >= ctx->S)
         return fail(FLUX_E_INVALID, "sets %llu + k*%llu (k<%llu) exceed the %u sample sets", (unsigned long long)first_set,
                     (unsigned long long)set_stride, (unsigned long long)num_sets, ctx->S);
-    if (ctx->N < 64 || ctx->variant == FLUX_KERNEL_STATIC || !FLUX_SET_GROUPED)
+    if (ctx->N < 64 || ctx->variant == FLUX_KERNEL_STATIC)
         return fail(FLUX_E_INVALID, "set-sharded rendering needs the refill kernel (sample_root^2 >= 64)");
     // every requested set must have its tables here: first_set + m*set_stride = sets.first + (slot_first + m*slot_stride)*sets.stride
     if (first_set < ctx->sets.first || (first_set - ctx->sets.first) % ctx->sets.stride != 0 ||

@@ -471,12 +471,6 @@ void build_wide(const std::vector<DevNode> &nodes, const std::vector<DevNodeQ> &
         sl[1] = slot_of(b, 1);
         while (n < 4) {  // open the inner child with the largest surface
             int pick = -1;
-#if FLUX_BVH_COLLAPSE_MODE == 2
-            // a subtree of at most four leaves becomes ONE node: open whatever inner child is left
-            if (leaves_below[(size_t)b] <= 4)
-                for (int k = 0; k < n; k++)
-                    if (sl[k].link >= 0) pick = k;
-#endif
 #if FLUX_BVH_COLLAPSE_MODE >= 1
             // ... but with the LAST free slot rather absorb a child whose own children are both leaves (a whole node less to visit)
             if (n == 3)

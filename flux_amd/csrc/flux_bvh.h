@@ -67,7 +67,7 @@ struct DevLeafRec {
 };
 static_assert(sizeof(DevLeafRec) == 128, "DevLeafRec layout");
 
-// ---- round 5: ONE stack entry per NODE instead of one per deferred child (FLUX_BVH4_ARENA = 1, the default) ---------------
+// ---- round 5: ONE stack entry per NODE instead of one per deferred child ------------------------------------
 // The per-lane LDS stack of the link layout above holds one entry per hit-but-deferred CHILD, so its bound is the sum of
 // (children - 1) along a path: 32 entries = 8 KiB per wave on the 1 M-triangle field, 7 LDS granules of 1 280 B, 18 waves per
 // CU instead of the 20 the kernel's registers allow.  Here a node's children are CONTIGUOUS in one arena of 64-B units --
@@ -97,9 +97,6 @@ FLUX_BVH_HD int32_t wide_link(uint32_t e, uint32_t k) {
     const uint32_t leaf = k >= n ? 0xffffffffu : 0u;
     return (int32_t)((f + k + ((k - (t & 6u)) & leaf)) ^ leaf);
 }
-#ifndef FLUX_BVH4_ARENA
-#define FLUX_BVH4_ARENA 1
-#endif
 
 constexpr int kBvhSahDepth = 32;    // below this depth the builder uses SAH, deeper: median splits
 constexpr int kBvhMaxDepth = 64;    // hard limit; the per-lane LDS stack is sized max_depth entries

@@ -6,61 +6,22 @@
 
 #include "flux_bvh.h"
 
-// hemi_sets layout: 1 = [S][D][N][4] (x,y,z,pad: one aligned 32-B sector per sample), 0 = [S][D][3][N] planes
-#ifndef FLUX_HEMI_AOS4
-#define FLUX_HEMI_AOS4 1
-#endif
+// Numeric tunables of the data layout / launch mapping (the boolean either/ors of rounds 1-5 are folded into the code: render.hip).
+// The render path as shipped: hemi_sets as [S][D][N][4] (one aligned 32-B sector per sample); waves ordered by sample set, one set
+// per XCD at a time (render_body.inc map_wave); FAST: the conservative f32 sphere filter, unit directions where the scene
+// guarantees them (RenderParams::unit_dirs), the self-skip of convex spheres (self_skip), the environment shortcut (env_short),
+// BoundingBox::hit's z-slab NaN miss reproduced by rule (box_z_nan_miss), the glossy lobe's sample-only factors tabulated
+// (RenderParams::gloss); mesh scenes on the 4-wide tree where its stack fits.
 
-// wave -> pixel order: 1 = grouped by sample set with one set per XCD at a time (render_body.inc map_wave), 0 = row-major
-// FAST scan: a ray leaving a convex sphere outwards skips that sphere (RenderParams::self_skip); up to FLUX_UNI_SPHERES
-// `invert` spheres are tested wave-uniformly instead of per lane (RenderParams::n_uni)
-#ifndef FLUX_SELF_SKIP
-#define FLUX_SELF_SKIP 1
-#endif
+// FAST scan: up to this many `invert` spheres are tested wave-uniformly instead of per lane (RenderParams::n_uni)
 #ifndef FLUX_UNI_SPHERES
 #define FLUX_UNI_SPHERES 2
 #endif
-// FAST: reproduce BoundingBox::hit's z-slab NaN miss (render_body.inc box_z_nan_miss); 0 only for A/B experiments
-#ifndef FLUX_Z_SLAB_RULE
-#define FLUX_Z_SLAB_RULE 1
-#endif
-// FAST scan: 1 = directions are taken as unit vectors where the scene guarantees it (RenderParams::unit_dirs)
-#ifndef FLUX_UNIT_DIRS
-#define FLUX_UNIT_DIRS 1
-#endif
-// FAST split kernel, phase B: 1 = an Emissive environment sphere is decided without its square root (RenderParams::env_short)
-#ifndef FLUX_ENV_SHORT
-#define FLUX_ENV_SHORT 1
-#endif
-// FAST mesh scenes: 1 = render_bvh4_kernel over the 4-wide tree (flux_bvh.h), 0 = render_bvh_kernel over the binary one
-#ifndef FLUX_BVH_WIDE
-#define FLUX_BVH_WIDE 1
-#endif
-// ... as long as its per-lane stack needs at most this many entries (48 x 256 B = 12 KiB of LDS per wave: 3 waves/SIMD)
+// FAST mesh scenes: render_bvh4_kernel over the 4-wide tree (flux_bvh.h) as long as its per-lane stack needs at most this many
+// entries (48 x 256 B = 12 KiB of LDS per wave: 3 waves/SIMD); deeper trees fall back to render_bvh_kernel over the binary one
 #ifndef FLUX_BVH_WIDE_MAX_STACK
 #define FLUX_BVH_WIDE_MAX_STACK 48
 #endif
-#ifndef FLUX_SET_GROUPED
-#define FLUX_SET_GROUPED 1
-#endif
-
-// FAST glossy lobe: 1 = the sample-only factors of to_unit_hemi (samplers/src/lib.rs:133-142) -- cos/sin of 2 pi x and
-// log2(1 - y) of the PIXEL sample, which GlossySpecular::sample_f (brdf.rs:64) re-maps at every bounce -- are computed
-// once per sample at table-build time (tables: `gloss` [S][N][4]); the render loop is left with one exp2 and a sqrt.
-#ifndef FLUX_GLOSS_TABLE
-#define FLUX_GLOSS_TABLE 1
-#endif
-
-// FAST sphere scan: 1 = the candidate filter runs in f32 on DevScanSphere32 records (conservative: see there)
-#ifndef FLUX_FILTER32
-#define FLUX_FILTER32 1
-#endif
-
-// split kernel, phase A: 1 = take the (normalised) primary direction as the unit direction of the sphere quadratic
-#ifndef FLUX_PRIMARY_UNIT
-#define FLUX_PRIMARY_UNIT 1
-#endif
-
 // refill kernel: most waves that share one pixel's samples (launch_render picks K <= this, a power of two)
 #ifndef FLUX_MAX_WAVES_PER_PIXEL
 #define FLUX_MAX_WAVES_PER_PIXEL 4
@@ -74,7 +35,7 @@
 
 namespace flux {
 
-constexpr int kHemiDoubles = FLUX_HEMI_AOS4 ? 4 : 3;  // doubles of hemi table per (set, depth, sample)
+constexpr int kHemiDoubles = 4;  // doubles of hemi table per (set, depth, sample): x, y, z, pad -- one aligned 32-B sector
 constexpr double kTMin = 0.0005;                       // constants.rs:4
 constexpr double kPi = 3.14159265358979323846264338327950288;
 constexpr double kInvPi = 1.0 / kPi;                   // constants.rs:5
@@ -190,7 +151,7 @@ struct RenderParams {
     const DevMaterial *mats;
     const double2 *pix;   // [S][N] (x,y)                 pixel_sets
     const double2 *disc;  // [S][N] (x,y)                 disc_sets
-    const double *hemi;   // hemi_sets: [S][D][N][4] (x,y,z,pad) -- or [S][D][3][N] planes with FLUX_HEMI_AOS4=0
+    const double *hemi;   // hemi_sets: [S][D][N][4] (x,y,z,pad)
     const double *gloss;  // [S][N][4] (cos 2 pi x, sin 2 pi x, log2(1 - y), pad) of pixel_sets (FAST glossy lobe)
     const int32_t *rowperm;  // [H][S] sample-set index per (row, col)
     const int32_t *invperm;  // [H][S] its inverse: the column that uses set s in a row
@@ -247,7 +208,7 @@ struct RenderParams {
     double fwx, fwy, fwz;
     const double *pxc;
     const DevSetRows *set_rows;  // [slots held]: the rows of pix / disc / hemi / gloss of each held set
-    // flux_math_coeffs.h kExp2Poly, for the glossy lobe's 2^x (render_body.inc FLUX_EXP2_ARGS): read with two scalar loads where the
+    // flux_math_coeffs.h kExp2Poly, for the glossy lobe's 2^x: read with two scalar loads where the
     // literals cost 24 s_mov_b32 per evaluation
     double exp2c[12];
 };

@@ -39,10 +39,14 @@
 #include "flux_math.h"
 #include "../../include/flux_abi.h"
 
-// Tunables (overridable with -D for experiments, scripts/sweep_variants.py).  Measured on demo2 at
-// 1024 spp (refill kernel): 256 threads x 2 waves/SIMD 88.6 ms; 256 x 3 71.7 ms; 64 x 3 70.7 ms;
-// 256 x 4 83.0 ms (spills).  Waves never cooperate, so one wave per block lets the LDS stack of a
-// finished wave be reused at once.
+// Tunables: NUMBERS only (overridable with -D, scripts/sweep_variants.py).  Every either/or of rounds 1-5 -- 45 boolean FLUX_*
+// switches with one shipped value and a measured verdict -- was folded into the code in round 6 (same ISA before and after,
+// profiles/r06_experiments/prune_flags/); the experiments' patches and logs stay under profiles/r0*_experiments/.  What is left
+// here, in flux_device.h (FLUX_UNI_SPHERES, FLUX_BVH_WIDE_MAX_STACK, FLUX_MAX_WAVES_PER_PIXEL, FLUX_MIN_SAMPLES_PER_WAVE) and in
+// bvh.cpp / flux_bvh.h (FLUX_BVH_BINS, FLUX_BVH_COLLAPSE_MODE, FLUX_BVH_LEAF), plus the six -DFLUX_DEBUG_* instrumentation hooks of
+// render_body.inc (never in the product build), is the whole list.
+// Block size: measured on demo2 at 1024 spp (refill kernel): 256 threads x 2 waves/SIMD 88.6 ms; 256 x 3 71.7 ms; 64 x 3 70.7 ms;
+// 256 x 4 83.0 ms (spills).  Waves never cooperate, so one wave per block lets the LDS stack of a finished wave be reused at once.
 #ifndef FLUX_BLOCK_THREADS
 #define FLUX_BLOCK_THREADS 64
 #endif
@@ -52,116 +56,26 @@
 #ifndef FLUX_WPE_BVH
 #define FLUX_WPE_BVH 4            // waves/SIMD of the binary-tree BVH kernel (the fallback): 4 waves, nothing spilled -- at 5 it spills 11 VGPRs
 #endif
-#ifndef FLUX_BVH4_PERM
-#define FLUX_BVH4_PERM 1          // render_bvh4_kernel's slab test: v_perm + magic-number planes + v_pk_fma_f32 (0: rotate + convert)
-#endif
-#ifndef FLUX_BVH4_SORT
-#define FLUX_BVH4_SORT 0          // render_bvh4_kernel: 1 = hit children fully sorted by entry distance; 0 = only the nearest is singled
-#endif                            //   out and the others stacked as they come (1024 spp: 165.7 -> 159.6 ms; 0.6 % more node visits)
 #ifndef FLUX_WPE_BVH4
 #define FLUX_WPE_BVH4 5           // waves/SIMD of render_bvh4_kernel: 96 VGPRs, nothing spilled, since round 4's register diet (before: 122 at 4)
 #endif
-#ifndef FLUX_BVH4_WAVE_TOTAL
-#define FLUX_BVH4_WAVE_TOTAL 1    // render_bvh4_kernel: 1 = a pixel's sum is kept per wave in scalar registers (6 VGPRs less, ~75 VALU instructions per shading pass more)
-#endif
-#ifndef FLUX_SHADE_TWO_PHASE
-#define FLUX_SHADE_TWO_PHASE 1    // FAST shade_hit: the bounce (and the only update of the loop-carried path state) under ONE `if` after the join of the
-#endif                            //   miss / emitter exits (render_body.inc shade_hit_fast), instead of early returns
-#ifndef FLUX_RELOAD_PARAMS
-#define FLUX_RELOAD_PARAMS 1      // render_refill_kernel, render_bvh_kernel: the same re-read of the kernel arguments per pass
-#endif
-#ifndef FLUX_SCALAR_VOTES
-#define FLUX_SCALAR_VOTES 1  // wave votes on boolean expressions written as scalar arithmetic on the lane masks of their compares (render_body.inc)
-#endif
-#ifndef FLUX_BVH4_TYP
-#define FLUX_BVH4_TYP 1  // render_bvh4_kernel: an instantiation with the usual analytic set's flags as compile-time constants
-#endif
-#ifndef FLUX_SPLIT_TYP
-#define FLUX_SPLIT_TYP 1  // render_split_kernel: a third instantiation with the usual scene's flags as compile-time constants
-#endif
-#ifndef FLUX_SPLIT_MAX32
-#define FLUX_SPLIT_MAX32 1  // render_split_kernel: a second instantiation for scenes of at most 32 spheres (one filter group, no group loop)
-#endif
-#ifndef FLUX_EXP2_ARGS
-#define FLUX_EXP2_ARGS 1  // FAST glossy lobe: the 2^x polynomial's coefficients from the kernel arguments (scalar loads) instead of literals
-#endif
-#ifndef FLUX_SET_ROWS
-#define FLUX_SET_ROWS 1  // FAST bounce / split kernel: a set's table rows from the context's DevSetRows record (one scalar load) instead of pointer + set * stride
-#endif
-#ifndef FLUX_SPLIT_UNIFORM_SUB
-#define FLUX_SPLIT_UNIFORM_SUB 1  // render_split_kernel: the wave's index in its block read into a scalar register (cursor / queue count in SGPRs)
-#endif
-#ifndef FLUX_SCALAR_LIVE
-#define FLUX_SCALAR_LIVE 0  // render_split_kernel: the lane mask of `live` kept in scalar registers; bit 0: the pop, 1: "a lane is free", 2: "no lane is live" use it
-#endif
-#ifndef FLUX_SPLIT_OPAQUE_UNIFORMS
-#define FLUX_SPLIT_OPAQUE_UNIFORMS 3  // render_split_kernel: bit 0 = the sample set, bit 1 = the sphere masks opaque per pass (no loop-invariant scalar pairs derived from them)
-#endif
-#ifndef FLUX_SPLIT_PIXEL_CONSTS
-#define FLUX_SPLIT_PIXEL_CONSTS 2  // render_split_kernel: primary_ray's per-pixel constants: 1 = kept in scalar registers, 2 = scalar loads from tables per pass
-#endif
-#ifndef FLUX_SPLIT_RELOAD_PARAMS
-#define FLUX_SPLIT_RELOAD_PARAMS 1 // render_split_kernel: kernel arguments re-read (scalar loads) in every pass instead of kept alive across the loop (38 SGPRs spilled to VGPR lanes)
-#endif
-#ifndef FLUX_BVH4_MAT_LIST
-#define FLUX_BVH4_MAT_LIST 0      // render_bvh4_kernel: 1 = a path's throughput as the list of its bounces' materials (1 VGPR, 8 gathers when the path
-                                  // ends: the vector-memory pipeline is what this kernel is short of), 0 = the running product (6 VGPRs).
-                                  // 1 M triangles @4096 spp, one box: list + per-lane sums 572.1, list + wave totals 583.5, product + wave totals 560.5 ms
-#endif
-#ifndef FLUX_BVH4_RELOAD_PARAMS
-#define FLUX_BVH4_RELOAD_PARAMS 1 // render_bvh4_kernel: kernel arguments re-read (scalar loads) in every pass instead of ~64 of them spilled to VGPR lanes
-#endif
-#ifndef FLUX_BVH4_EARLY_REFILL
-#define FLUX_BVH4_EARLY_REFILL 1  // render_bvh4_kernel: the node loop is left for the shading step as soon as FLUX_BVH_REFILL_AT walks have ended
-#endif
 #ifndef FLUX_BVH4_EARLY_AT
-#define FLUX_BVH4_EARLY_AT 48     //   ... that many
-#endif
-#ifndef FLUX_BVH4_ENTRY
-#define FLUX_BVH4_ENTRY 1         // render_bvh4_kernel: a pixel's camera rays enter the tree where its ray bundle first reaches two children
+#define FLUX_BVH4_EARLY_AT 48     // render_bvh4_kernel leaves its node loop for the shading step as soon as this many walks have ended
 #endif
 #ifndef FLUX_BVH_REFILL_AT
 #define FLUX_BVH_REFILL_AT 40     // lanes that must be waiting for shading before the wave leaves traversal (swept 16..64 with the leaf vote)
 #endif
 // the early exit leaves the node loop when EARLY_AT walks have ended and expects the shading step to follow: with
 // EARLY_AT < REFILL_AT the wave would re-enter the loop on the same counts and never advance
-static_assert(!FLUX_BVH4_EARLY_REFILL || FLUX_BVH4_EARLY_AT >= FLUX_BVH_REFILL_AT,
+static_assert(FLUX_BVH4_EARLY_AT >= FLUX_BVH_REFILL_AT,
               "FLUX_BVH4_EARLY_AT must not be below FLUX_BVH_REFILL_AT (render_bvh4_kernel would livelock)");
 #ifndef FLUX_WPE_SPLIT
 #define FLUX_WPE_SPLIT 5          // waves/SIMD of the split kernel: 96 VGPRs, nothing spilled since round 4 (4 until then: 128 VGPRs); demo2 @16384 spp 250.0 -> 225.4 ms
 #endif
-#ifndef FLUX_BVH_LEAF_VOTE
-#define FLUX_BVH_LEAF_VOTE 1      // leave the inner-node loop once the lanes holding a leaf outweigh the descending ones
-#endif
 #ifndef FLUX_BVH_LEAF_NUM
-#define FLUX_BVH_LEAF_NUM 2       // ... i.e. when n_leaf * NUM > n_inner * DEN (re-swept after the node step got cheaper: 1:1 178.4,
-#define FLUX_BVH_LEAF_DEN 3       //     2:3 175.9, 1:2 176.4, 1:3 179.7, 3:2 178.8 ms at 1024 spp)
+#define FLUX_BVH_LEAF_NUM 2       // binary-tree kernel: the inner-node loop is left once the lanes holding a leaf outweigh the descending ones,
+#define FLUX_BVH_LEAF_DEN 3       //     n_leaf * NUM > n_inner * DEN (swept: 1:1 178.4, 2:3 175.9, 1:2 176.4, 1:3 179.7, 3:2 178.8 ms at 1024 spp)
 #endif
-#ifndef FLUX_STRICT_BOX_HWMINMAX
-#define FLUX_STRICT_BOX_HWMINMAX 1 // STRICT BoundingBox::hit: the reference's min / max forms through v_min_f64 / v_max_f64 + one unordered compare
-#endif                             //   of the z slab (the same verdict bit for bit, render_body.inc scene_hit)
-#ifndef FLUX_BVH4_LDS_SCENE
-#define FLUX_BVH4_LDS_SCENE 1      // render_bvh4_kernel: the analytic set's hit records, the materials and the scan spheres in the block's LDS while they are small
-                                   //   (stack + records <= 7 680 B, the 6 granules of 5 waves per SIMD: its own instantiation): the shading step's dependent gathers lose an L2 round trip; 1 M triangles 542.0 -> 530.9 ms
-#endif
-#ifndef FLUX_TRI_FDIV
-#define FLUX_TRI_FDIV 0            // FAST triangle test: 1 / det by fastmath::fdiv (<= 2 ulp) instead of the IEEE division: measured SLOWER (548.3 against 542.3 ms), off
-#endif
-#ifndef FLUX_TRAV_RCP32
-#define FLUX_TRAV_RCP32 1          // BVH kernels: the slab test's 1 / d from v_rcp_f32 instead of three IEEE f64 divisions per ray segment
-#endif
-#ifndef FLUX_SPLIT_EARLY_SAMPLES
-#define FLUX_SPLIT_EARLY_SAMPLES 0 // render_split_kernel: phase A's pixel / lens samples requested before the queue pop (experiment, round 5)
-#endif
-#ifndef FLUX_SPLIT_LDS_SCENE
-#define FLUX_SPLIT_LDS_SCENE 2     // render_split_kernel: hit records + scan spheres copied into the block's LDS: the per-lane gathers in the middle of a
-                                   //   pass become LDS reads (round 5: the chip runs the kernel at 2.37 GHz and its VALU idles ~14 % of the cycles -- all
-                                   //   resident waves waiting on memory at once); demo2 @16384 spp 227.3 -> 222.6 ms.  2 = the records FIRST in the
-                                   //   dynamic LDS (an address the compiler knows: no scalar register holds it), the queues behind them: 215.4 -> 214.9 ms
-#endif
-#ifndef FLUX_STRICT_FILTER
-#define FLUX_STRICT_FILTER 1       // STRICT Scene::hit: BoundingBox::hit + Sphere::hit only for the spheres FAST's conservative f32 filter passes
-#endif                             //   (a rejected sphere's quadratic says miss whatever its box says): the same frames bit for bit
 #ifndef FLUX_STRICT_SCAN_UNROLL
 #define FLUX_STRICT_SCAN_UNROLL 4  // STRICT shape scan: records fetched this many at a time (scalar loads issued together); demo2 @16384 spp 1035 -> 1026 ms
 #endif
@@ -198,7 +112,7 @@ namespace fast {
 #include "render_body.inc"
 }  // namespace fast
 }  // namespace flux
-// FAST glossy-lobe factors of every pixel sample (flux_device.h FLUX_GLOSS_TABLE), compiled with the FAST arithmetic
+// FAST glossy-lobe factors of every pixel sample (RenderParams::gloss), compiled with the FAST arithmetic
 // so that the table holds bit for bit what to_unit_hemi would compute inline.
 namespace flux {
 __global__ void gloss_fill_kernel(const double2 *__restrict__ pix, size_t count, double *__restrict__ gloss) {

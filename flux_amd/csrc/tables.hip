@@ -140,30 +140,16 @@ __global__ void hemi_fill_kernel(uint64_t seed, SetRange sets, uint32_t D, uint3
     uint32_t d = (uint32_t)(sd % D), s = (uint32_t)(sd / D);
     uint32_t i = p / n, k = p % n;
     const uint16_t *pb = perms + sd * (2ull * n) * n;
-#ifdef FLUX_EXP_HEMI_CMJ
-    // EXPERIMENT (scripts/ref16_variance.py, never the product build): ONE y- and ONE x-permutation per grid, i.e. the
-    // correlated variant's structure (lib.rs:75-90) for the hemisphere stream, to test what it does to the variance
-    uint32_t yk = pb[k];
-    uint32_t xi = pb[(size_t)n * n + i];
-#else
     uint32_t yk = pb[(size_t)i * n + k];        // y-shuffle of row i, element k
     uint32_t xi = pb[((size_t)n + k) * n + i];  // x-shuffle of column k, element i
-#endif
     double2 q = mj_point(stream_key(seed, kKindHemi, global_set(sets, s), d, kSubJitter), n, i, k, xi, yk);
     double pu, pv, pw;
     unit_hemi_e0(q, pu, pv, pw);
-#if FLUX_HEMI_AOS4
     double *o = out + (sd * N + p) * 4;  // [S][D][N][4]: one 32-B sector per sample
     o[0] = pu;
     o[1] = pv;
     o[2] = pw;
     o[3] = 0.0;
-#else
-    double *o = out + sd * 3 * N;
-    o[p] = pu;
-    o[N + p] = pv;
-    o[2 * N + p] = pw;
-#endif
 }
 
 // SoA [S][D][3][N] -> reference order [S][D][N][3] (introspection only)
@@ -172,17 +158,10 @@ __global__ void hemi_to_aos_kernel(size_t SD, size_t N, const double *__restrict
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= SD * N) return;
     size_t sd = t / N, p = t % N;
-#if FLUX_HEMI_AOS4
     const double *b = in + (sd * N + p) * 4;
     out[t * 3] = b[0];
     out[t * 3 + 1] = b[1];
     out[t * 3 + 2] = b[2];
-#else
-    const double *b = in + sd * 3 * N;
-    out[t * 3] = b[p];
-    out[t * 3 + 1] = b[N + p];
-    out[t * 3 + 2] = b[2 * N + p];
-#endif
 }
 
 // One set of any of the samplers crate's four generators (sampler-debug/src/main.rs:48-57) and, optionally,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-basic-block map of a kernel's assembly (scripts/kernel_regs.py <kernel> --asm out.s): instructions, VALU / VMEM / LDS
+"""Per-basic-block map of a kernel's assembly (scripts/kernel_asm.py <kernel> --asm out.s): instructions, VALU / VMEM / LDS
 counts, distinct VGPRs referenced and the highest one -- where a kernel's register peak sits.  usage: asm_blocks.py out.s [min_insts]"""
 import re
 import sys

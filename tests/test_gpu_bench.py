@@ -36,6 +36,17 @@ def test_bench_line_contract():
     assert one["cores"] == 1 and one["kind"] == "port" and one["value"] > 0 and "16 spp" in one["sample"]
     assert d["roofline"]["kernel"] == "render_split_kernel" and d["config"]["waves_per_pixel"] == 1
     assert d["rccl_probe"]["ran"] is True and d["rccl_probe"]["backend"] == "nccl" and d["rccl_probe"]["all_gather_equals_local"] is True
+    # round 6: the same frame through the C ABI's multi-GPU entry (RCCL from C, G = 1), bit-equal to the timed frame
+    m = d["multi_abi"]
+    assert m["ran"] is True and m["devices"] == 1 and m["rccl_version"] >= 20000 and m["frame_equals_timed_frame"] is True
+    assert m["kernel_ms"] > 0 and m["frame_ms"] >= m["kernel_ms"]
+    # ... context creation as the reference's timer sees it: a running worker's (warm), the process's first (cold), the breakdown
+    assert 0 < d["ctx_create_ms"] <= d["ctx_create_cold_ms"]
+    b = d["ctx_create_breakdown_ms"]
+    assert abs(sum(v for k, v in b.items() if k != "total") - b["total"]) < 0.01 and b["tables"] > 0
+    assert d["reference_equivalent_s"] <= d["reference_equivalent_cold_s"]
+    assert d["build_id"].startswith("lib:") and "kernels:" in d["build_id"]
+    assert d["roofline"]["profile_matches_build"] in (True, False, None)
 
 
 @pytest.mark.parametrize("shard", ["sets", "rows"])

@@ -528,7 +528,7 @@ def test_strict_filter_equals_the_full_scan(flux, demo1, demo2):
     filter is not defined for (a coordinate beyond 1e15) -- so the same scene with one unreachable sphere at x = 1e16 appended
     (last: nobody's YAML index moves) renders through it: frames and path statistics equal bit for bit, demo1, demo2 and fuzz
     scenes with inverted spheres, coincident twins and non-unit planes, static and refill kernels.
-    (scripts/strict_filter_check.py does the same against a -DFLUX_STRICT_FILTER=0 build of the library.)"""
+    (Round 5 did the same against a build without the filter: profiles/r05_experiments/strict_filter_check*.log.)"""
     import copy
     from test_gpu_fuzz import random_scene
     scenes = [(small_scene(demo1, 96, 72), 8, 5, 1), (small_scene(demo2, 96, 72), 8, 5, 2)]
