@@ -24,6 +24,7 @@ NUM_STATS = 16
 BVH_INFO_WORDS = 16
 PLAN_WORDS = 8
 PLAN_NONE, PLAN_STATIC, PLAN_REFILL, PLAN_SPLIT, PLAN_BVH_BINARY, PLAN_BVH4 = -1, 0, 1, 2, 3, 4
+ROUTE_NONE, ROUTE_TO_STRICT, ROUTE_KEPT_FAST = 0, 1, 2
 CREATE_TIMING_WORDS = 8
 CREATE_TIMING_NAMES = ("total", "host", "runtime", "alloc", "upload", "tables", "free", "other")
 SHARD_AUTO, SHARD_SETS, SHARD_ROWS = 0, 1, 2

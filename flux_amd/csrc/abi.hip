@@ -273,9 +273,15 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         const flux::DevMaterial &m = mats[i];
         flux::DevHitRec r;
         std::memset(&r, 0, sizeof(r));
-        r.fr = m.fr; r.fg = m.fg; r.fb = m.fb;
-        r.exponent = m.exponent; r.inv_e1 = m.inv_e1;
-        r.shape_kind = d.kind; r.mat_kind = m.kind; r.exp_parity = m.exp_parity; r.orig_id = (int32_t)i;
+        // (the FAST bounce weight: flux_device.h DevHitRec; the product is the one the kernels formed per bounce, `fr * scale`)
+        const double wsc = m.kind == flux::kMatMatte ? 1.0 / flux::kInvPi : 1.0;
+        r.fr = m.kind == flux::kMatMatte ? m.fr * wsc : m.fr;
+        r.fg = m.kind == flux::kMatMatte ? m.fg * wsc : m.fg;
+        r.fb = m.kind == flux::kMatMatte ? m.fb * wsc : m.fb;
+        r.inv_e1 = m.inv_e1;
+        r.ax = m.kind == flux::kMatMatte ? 0.0034 : 0.00424;  // brdf.rs:22 / brdf.rs:58
+        r.az = m.kind == flux::kMatMatte ? 0.0071 : 0.00764;
+        r.shape_kind = d.kind; r.mat_kind = m.kind; r.orig_id = (int32_t)i;
         // spheres: |(hit - centre) / radius| = 1 to rounding; planes use the stored normal as is (shapes.rs:135-152)
         r.unit_normal = d.kind == flux::kShapeSphere ||
                         std::fabs((d.c0x * d.c0x + d.c0y * d.c0y + d.c0z * d.c0z) - 1.0) <= 4.0 * 2.220446049250313e-16;
@@ -644,9 +650,11 @@ static bool holds_all_sets(const flux_ctx *c) { return c->sets.stride == 1 && c-
 // holds 31 levels beside nothing else), FAST keeps none.  A FAST job deeper than that, on such a scene, stays with FAST and its
 // long-form glossy weights (RenderParams::glossy_long; what every FAST render of such a scene was before round 4: the
 // reference's NaN pixels in all but the rarest orderings of an overflow and a zero) instead of being refused.
+// (a function of the JOB alone -- max_trace_depth and the mesh's BVH depth --, not of flux_ctx_set_traversal: the arithmetic a scene
+// is rendered with must not flip with a test hook; a brute-force traversal leaves the BVH stack's bytes unused)
 static bool strict_fits_lds(const flux_ctx *ctx) {
     const size_t stack = (size_t)ctx->D * 4 * 64 * sizeof(double);
-    const size_t bvh = (ctx->rp.n_tris > 0 && ctx->traversal != FLUX_TRAVERSE_BRUTE) ? (size_t)ctx->bvh.max_depth * 64 * sizeof(int) : 0;
+    const size_t bvh = ctx->rp.n_tris > 0 ? (size_t)ctx->bvh.max_depth * 64 * sizeof(int) : 0;
     return stack + bvh + 512 <= 64 * 1024;  // (the smallest block the planner can choose: one wave; plan_render_impl)
 }
 static int effective_math(const flux_ctx *ctx) {
@@ -833,7 +841,10 @@ int flux_ctx_launch_plan(flux_ctx *ctx, uint64_t num_rows, uint64_t num_sets, in
     out[3] = (int64_t)L.lds;
     out[4] = L.waves_per_pixel;
     out[5] = effective_math(ctx);
-    out[6] = out[7] = 0;
+    // why the arithmetic is not the requested one, or why it SHOULD not be: a FAST job on a scene with a non-unit plane normal
+    out[6] = (ctx->math == FLUX_MATH_FAST && ctx->rp.glossy_long) ? (strict_fits_lds(ctx) ? FLUX_ROUTE_TO_STRICT : FLUX_ROUTE_KEPT_FAST)
+                                                                 : FLUX_ROUTE_NONE;
+    out[7] = 0;
     return FLUX_OK;
 }
 

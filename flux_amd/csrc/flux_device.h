@@ -110,12 +110,18 @@ static_assert(sizeof(DevScanPlane) == 64, "DevScanPlane layout");
 struct DevHitRec {      // 96 B
     double cx, cy, cz;  // sphere centre | plane normal
     double inv_rad;     // sphere: invert_val / radius
-    double fr, fg, fb;  // material constants as in DevMaterial
-    double exponent, inv_e1;
+    // Emissive: the emitted radiance color * power (materials.rs:45).  Every other material: the FAST bounce weight f (n.wi)/pdf in
+    // its closed form -- f / INV_PI for Matte (f = diffuse_color kd INV_PI, brdf.rs:30: the same two IEEE multiplications the kernels
+    // performed per bounce until round 6, done once on the host), f itself for Reflective / Glossy (DevMaterial keeps the plain f)
+    double fr, fg, fb;
+    double inv_e1;      // Glossy: 1 / (exponent + 1); the exponent itself and its parity: DevMaterial (mats[orig_id]), long-form lobes only
     int32_t shape_kind, mat_kind;
-    int32_t exp_parity, orig_id;
+    int32_t orig_id;      // index in YAML order (the tie rule's key; also the shape's material index)
     int32_t unit_normal;  // 1: the hit normal has length 1 to rounding (every sphere; a plane whose stored normal does)
-    int32_t pad;
+    // x and z of the helper vector a = (ax, 1, az) the lobe's frame is built around: (0.0034, 1, 0.0071) for Matte (brdf.rs:22),
+    // (0.00424, 1, 0.00764) otherwise (brdf.rs:58) -- per-lane constants that cost a dozen register moves per bounce when selected
+    // by material kind in the kernel
+    double ax, az;
 };
 static_assert(sizeof(DevHitRec) == 96, "DevHitRec layout");
 

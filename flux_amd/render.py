@@ -43,6 +43,15 @@ class Renderer:
         instead of being found by polling launch_plan()["math"]."""
         if getattr(self, "_routed_warned", False):
             return
+        if self.launch_plan(num_rows=1)["route"] == _lib.ROUTE_KEPT_FAST:
+            # the other side of the same rule (ADVICE round 5): the scene wants STRICT, the job is too deep for it
+            self._routed_warned = True
+            import warnings
+            warnings.warn("flux_amd: this scene has a plane stored with a non-unit normal, but max_trace_depth leaves no room for the "
+                          "STRICT arithmetic's recursion stack (31 levels of LDS, fewer with a mesh): the job stays on FLUX_MATH_FAST "
+                          "with long-form glossy weights, and pixels the reference renders as NaN may come out finite. Normalise the "
+                          "plane normals or lower max_trace_depth.", RuntimeWarning, stacklevel=3)
+            return
         if self.requested_math == _lib.MATH_FAST and self.effective_math() == _lib.MATH_STRICT:
             self._routed_warned = True
             import warnings
@@ -183,7 +192,7 @@ class Renderer:
         (flux_render_sets_device) when num_sets > 0."""
         buf = (C.c_int64 * _lib.PLAN_WORDS)()
         _lib.check(_lib.lib.flux_ctx_launch_plan(self._handle(), self.height if num_rows is None else num_rows, num_sets, buf))
-        names = ("kernel", "block", "blocks", "lds", "waves_per_pixel", "math")
+        names = ("kernel", "block", "blocks", "lds", "waves_per_pixel", "math", "route")
         return dict(zip(names, [int(x) for x in buf]))
 
     def table(self, which: int) -> np.ndarray:

@@ -271,7 +271,15 @@ int flux_ctx_bvh_info(flux_ctx *ctx, uint64_t *out, uint64_t out_words);
  * out[0] kernel (FLUX_PLAN_*), [1] threads per block, [2] blocks, [3] dynamic LDS bytes per block,
  * [4] waves that share one pixel's samples (K: 1, 2 or 4 -- from the sample count, and in the STRICT arithmetic the LDS its
  * recursion stack leaves), [5] the arithmetic the launch runs with (FLUX_MATH_*: STRICT also under FLUX_MATH_FAST when the
- * scene has a plane with a non-unit normal, see flux_ctx_set_math), [6..7] reserved (0). */
+ * scene has a plane with a non-unit normal, see flux_ctx_set_math), [6] FLUX_ROUTE_*: NONE; TO_STRICT = FLUX_MATH_FAST was
+ * requested, the scene has a plane with a non-unit normal, the launch runs STRICT (several times slower); KEPT_FAST = the same
+ * scene, but max_trace_depth (and the mesh's BVH depth) leave no room for STRICT's LDS recursion stack, so the job stays FAST
+ * with the reference's long-form glossy weights -- its pixels can differ from the reference's NaN pixels in the rarest orderings
+ * of an overflow and a zero.  The decision depends on the job alone, not on flux_ctx_set_traversal.
+ * [7] reserved (0). */
+#define FLUX_ROUTE_NONE 0
+#define FLUX_ROUTE_TO_STRICT 1
+#define FLUX_ROUTE_KEPT_FAST 2
 #define FLUX_PLAN_NONE (-1)    /* nothing to launch */
 #define FLUX_PLAN_STATIC 0     /* render_static_kernel */
 #define FLUX_PLAN_REFILL 1     /* render_refill_kernel */

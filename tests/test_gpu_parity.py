@@ -495,6 +495,7 @@ def test_a_job_too_deep_for_strict_stays_fast_on_a_non_unit_plane(flux, oracle_m
         warnings.simplefilter("always")
         with flux.Renderer(sd, flux.JobConfiguration(8, 5, 50), seed=9) as r:      # depth 5: STRICT fits, the routing applies
             assert r.launch_plan()["math"] == flux.MATH_STRICT and "FAST -> STRICT" in repr(r)
+            assert r.launch_plan()["route"] == flux._lib.ROUTE_TO_STRICT
         assert sum("non-unit normal" in str(x.message) for x in w) == 1
     cfg = flux.JobConfiguration(16, 40, 50)
     o = oracle_mod.Oracle(sd, cfg, seed=9)
@@ -505,6 +506,7 @@ def test_a_job_too_deep_for_strict_stays_fast_on_a_non_unit_plane(flux, oracle_m
         warnings.simplefilter("always")
         with flux.Renderer(sd, cfg, seed=9) as r:
             assert r.launch_plan()["math"] == flux.MATH_FAST and "->" not in repr(r)
+            assert r.launch_plan()["route"] == flux._lib.ROUTE_KEPT_FAST      # (said out loud, see the warning below)
             assert r.launch_plan()["kernel"] == flux._lib.PLAN_SPLIT          # 256 spp: the default kernel, long-form glossy weights
             r.enable_stats(True)
             for variant in (flux.KERNEL_DEFAULT, flux.KERNEL_REFILL, flux.KERNEL_STATIC):
@@ -518,7 +520,85 @@ def test_a_job_too_deep_for_strict_stays_fast_on_a_non_unit_plane(flux, oracle_m
             r.set_math(flux.MATH_STRICT)
             with pytest.raises(flux.FluxError, match="FLUX_MATH_FAST or a smaller max_trace_depth"):
                 r.render_frame()
-        assert not any("non-unit normal" in str(x.message) for x in w)
+        # the job that STAYS on FAST although the scene asks for STRICT is reported too, once, in its own words
+        kept = [str(x.message) for x in w if "non-unit normal" in str(x.message)]
+        assert len(kept) == 1 and "stays on FLUX_MATH_FAST" in kept[0], kept
+    with flux.Renderer(small_scene(demo2, 32, 24), cfg, seed=9) as r:              # unit normals: nothing to route, nothing to say
+        assert r.launch_plan()["route"] == flux._lib.ROUTE_NONE
+
+
+def test_routing_to_strict_does_not_depend_on_the_traversal_hook(flux, demo2):
+    """the arithmetic a scene is rendered with is a function of the job (max_trace_depth, the mesh's BVH depth), never of
+    flux_ctx_set_traversal -- a test hook must not flip the frame.  A mesh scene with a non-unit plane normal at a depth where STRICT's
+    recursion stack fits only WITHOUT the BVH stack beside it: before, the brute-force hook made it fit and routed the job to STRICT."""
+    import copy
+    from flux_amd.procedural import heightfield_scene
+    sd = copy.deepcopy(heightfield_scene(24, 16, seed=5, base=small_scene(demo2, 24, 18)))
+    plane = next(s for s in sd.shapes if isinstance(s, flux.PlaneData))
+    plane.normal = tuple(1.3 * x for x in plane.normal)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with flux.Renderer(sd, flux.JobConfiguration(8, 31, 50), seed=2) as r:
+            depth = r.bvh_info()["max_depth"]
+            fits = 31 * 4 * 64 * 8 + depth * 64 * 4 + 512 <= 64 * 1024
+            plans = {}
+            for mode in (flux._lib.TRAVERSE_BVH, flux._lib.TRAVERSE_BRUTE, flux._lib.TRAVERSE_BVH_BINARY):
+                r.set_traversal(mode)
+                plans[mode] = (r.launch_plan()["math"], r.launch_plan()["route"])
+            assert len(set(plans.values())) == 1, plans
+            assert plans[flux._lib.TRAVERSE_BVH] == ((flux.MATH_STRICT, flux._lib.ROUTE_TO_STRICT) if fits else
+                                                     (flux.MATH_FAST, flux._lib.ROUTE_KEPT_FAST)), (plans, depth)
+
+
+def test_split_kernel_serves_scenes_with_many_planes(flux, oracle_mod, demo1):
+    """the split kernel keeps the scene's records in LDS and used to leave any scene with more than 16 planes to the refill
+    kernel without a word.  The rule is now by bytes (records <= 16 KiB): 64 spheres + 20 planes run the split kernel -- and meet the oracle,
+    statistics included --, 65 spheres (the pixel mask's width) or 200 planes take the refill kernel, and the launch plan says which."""
+    import copy
+    rng = np.random.default_rng(7)
+    base = copy.deepcopy(small_scene(demo1, 40, 30))
+
+    def scene(n_sph, n_pln):
+        sd = copy.deepcopy(base)
+        shapes = [sd.shapes[0]]  # the inverted environment sphere
+        for k in range(n_sph - 1):
+            m = (flux.MatteData((0.6, 0.5, 0.4), (0, 0, 0), 0.8) if k % 3 == 0 else
+                 flux.GlossyReflectiveData(0.7, (0.9, 0.8, 0.9), float([10.0, 100.0, 1e4][k % 3])) if k % 3 == 1 else
+                 flux.ReflectiveData(0.8, (0.9, 0.9, 1.0)))
+            shapes.append(flux.SphereData((float(rng.uniform(-4, 9)), float(rng.uniform(0.2, 3.0)), float(rng.uniform(-3, 12))),
+                                          float(rng.uniform(0.2, 0.9)), m, False))
+        for k in range(n_pln):  # tilted floors and walls, unit normals (FAST stays FAST)
+            n = np.array([rng.uniform(-0.3, 0.3), 1.0, rng.uniform(-0.3, 0.3)])
+            n /= np.linalg.norm(n)
+            shapes.append(flux.PlaneData((0.0, float(-0.2 - 0.3 * k), 0.0), tuple(float(x) for x in n),
+                                         flux.MatteData((0.5, 0.5, 0.5), (1, 1, 1), 1.0)))
+        sd.shapes = shapes
+        return sd
+
+    cfg = flux.JobConfiguration(16, 5, 50)   # 256 spp: the split kernel's range
+    sd = scene(64, 20)
+    o = oracle_mod.Oracle(sd, cfg, seed=4)
+    o.stats(reset=True)
+    want = o.render_frame(threads=8)
+    ost = o.stats()
+    o.close()
+    with flux.Renderer(sd, cfg, seed=4) as r:
+        plan = r.launch_plan()
+        assert plan["kernel"] == flux._lib.PLAN_SPLIT and plan["math"] == flux.MATH_FAST, plan
+        assert plan["lds"] >= (64 + 20) * 96 + 64 * 32
+        r.enable_stats(True)
+        r.stats(reset=True)
+        got = r.render_frame()
+        st = r.stats()
+        assert {k: st[k] for k in ost} == ost
+        assert max_abs_diff(got, want) < TOL_IMAGE
+        r.set_kernel(flux.KERNEL_REFILL)
+        assert max_abs_diff(r.render_frame(), got) < 1e-12
+    for n_sph, n_pln in ((65, 1), (12, 200)):
+        with flux.Renderer(scene(n_sph, n_pln), cfg, seed=4) as r:
+            assert r.launch_plan()["kernel"] == flux._lib.PLAN_REFILL, (n_sph, n_pln)
+            assert np.isfinite(r.render_frame()).all()
 
 
 def test_strict_filter_equals_the_full_scan(flux, demo1, demo2):
