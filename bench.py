@@ -62,6 +62,10 @@ def parse():
                     help="render arithmetic (include/flux_abi.h FLUX_MATH_*); both are FP64 and parity-tested")
     ap.add_argument("--shard", default="auto", choices=["auto", "rows", "sets"],
                     help="how the frame is split over GPUs: interleaved rows, or sample sets (default)")
+    ap.add_argument("--abi-multi", action="store_true",
+                    help="ONE process driving --gpus N devices through the C ABI's multi-GPU entry (flux_multi_*: per-device contexts, one "
+                         "launch per device, ncclAllGather from RCCL's C API) instead of N torch.distributed ranks: what a compiled "
+                         "embedder (the reference's Rust host, the C++ `flux --split sets`) runs.  Prints the same kind of line.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rccl-probe", action="store_true",
                     help="skip the world-size-1 RCCL child after the timed region (profiling passes: a second GPU process under "
@@ -288,8 +292,67 @@ def phase(rank, world, what):
         print(f"bench.py rank {rank}/{world}: {line}", file=sys.stderr, flush=True)
 
 
+def abi_multi_main(a):
+    """`bench.py --abi-multi --gpus N`: the frame of every step comes from flux_multi_render_frame_device (left in HBM on device 0)."""
+    import flux_amd
+    sd = flux_amd.load_scene(os.path.join(ROOT, "scenes", f"{a.scene}.yml"))
+    W, H = sd.output_settings.image_width, sd.output_settings.image_height
+    n = a.root
+    cfg = flux_amd.JobConfiguration(n, a.depth, 50)
+    shard = {"auto": flux_amd.SHARD_AUTO, "sets": flux_amd.SHARD_SETS, "rows": flux_amd.SHARD_ROWS}[a.shard]
+    sys.stdout.flush()
+    saved = os.dup(1)   # RCCL's banner goes to stdout: keep it off the ONE JSON line
+    os.dup2(2, 1)
+    try:
+        t0 = time.perf_counter()
+        m = flux_amd.MultiRenderer(sd, cfg, seed=a.seed, devices=list(range(a.gpus)), shard=shard)
+        t_create = time.perf_counter() - t0
+        m.set_kernel(a.kernel)
+        m.set_math(flux_amd.MATH_FAST if a.math == "fast" else flux_amd.MATH_STRICT)
+        for _ in range(a.warmup):
+            m.render_frame_device()
+        spans = []
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            m.render_frame_device()
+            spans.append(m.timing())
+        elapsed = time.perf_counter() - t0
+        frame = m.render_frame()
+        info = m.info()
+        plan = m.rank_renderer(0).launch_plan(num_sets=len(range(0, W, a.gpus))) if info["shard"] == flux_amd.SHARD_SETS else \
+            m.rank_renderer(0).launch_plan(num_rows=len(range(0, H, a.gpus)))
+        m.close()
+        flux_amd.release_comms()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    import numpy as np
+    samples = W * H * n * n
+    mean = {k: sum(s[k] for s in spans) / max(len(spans), 1) for k in spans[0]}
+    out = {"metric": f"Msamples/sec on {a.scene}.yml (fixed spp)", "value": round(samples * a.steps / elapsed / 1e6, 3), "unit": "Msamples/s",
+           "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"scenes/{a.scene}.yml {W}x{H} at {n * n} spp (sample_root {n}), depth {a.depth}, seed {a.seed}",
+                      "parallelism": f"C ABI flux_multi_*: ONE process, {a.gpus} device(s), "
+                                     f"{'pixel-set' if info['shard'] == flux_amd.SHARD_SETS else 'row-interleaved'} tiles, 1 ncclAllGather (RCCL "
+                                     f"{info['rccl_version']}), reassembly on device 0", "math": a.math, "finite": bool(np.isfinite(frame).all()),
+                      "waves_per_pixel": plan["waves_per_pixel"], "blocks_per_launch": plan["blocks"]},
+           "step_breakdown_ms": {"render": round(mean["kernel_ms"], 3), "all_gather": round(mean["all_gather_ms"], 3),
+                                 "reassembly": round(mean["reassembly_ms"], 3), "frame_call": round(mean["frame_ms"], 3),
+                                 "note": "flux_multi_timing: the slowest rank's kernel (HIP events on its stream), the all-gather and the "
+                                         "reassembly on device 0's stream, wall time of the render call"},
+           "multi_create_ms": round(t_create * 1e3, 1), "multi_info": info,
+           "build_id": (flux_amd._lib.lib.flux_build_id() or b"").decode(),
+           "roofline": None, "cpu_baseline": None,
+           "note": "the C-ABI multi-GPU path; the roofline / cpu_baseline objects are in the default (torch.distributed) line"}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
+    if a.abi_multi:
+        return abi_multi_main(a)
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a.gpus))
     rank = int(os.environ.get("RANK", "0"))

@@ -305,6 +305,24 @@ class MultiRenderer:
         _lib.check(_lib.lib.flux_multi_ctx(self._handle(), rank, C.byref(h)))
         return _create_timing(h)
 
+    def rank_renderer(self, rank: int = 0) -> "Renderer":
+        """Rank's context as a Renderer (BORROWED: flux_multi_ctx; closing it does nothing) -- for launch_plan, statistics, tables."""
+        h = C.c_void_p()
+        _lib.check(_lib.lib.flux_multi_ctx(self._handle(), rank, C.byref(h)))
+        r = _BorrowedRenderer.__new__(_BorrowedRenderer)
+        r.scene_data, r.config, r.seed, r.device = self.scene_data, self.config, self.seed, self.devices[rank]
+        r.width, r.height = self.width, self.height
+        info = self.info()
+        r.set_share = (rank, len(self.devices)) if info["shard"] == _lib.SHARD_SETS else (0, 1)
+        r._h = h
+        r._routed_warned = True
+        return r
+
+
+class _BorrowedRenderer(Renderer):
+    def close(self):
+        self._h = None
+
 
 def render_frame_multi(scene_data: SceneData, config: JobConfiguration, seed: int = 1, num_devices: int = 0,
                        shard: int = _lib.SHARD_AUTO) -> np.ndarray:

@@ -88,3 +88,19 @@ def test_bench_multi_rank_branch_rehearsal(shard):
     for rk in (0, 1):
         for what in ("process group up (gloo)", "ctx created", "warm-up done", "timed 2 steps", "done"):
             assert any(f"rank {rk}/2" in l and what in l for l in p.stderr.splitlines()), (rk, what, p.stderr[-1500:])
+
+
+def test_bench_abi_multi_mode():
+    """`bench.py --abi-multi --gpus 1`: one process, the C ABI's multi-GPU entry (flux_multi_*, RCCL from C) instead of torch.distributed
+    ranks -- the mode a node with several GPUs is driven in by a compiled embedder; one JSON line, nothing else on stdout."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--abi-multi", "--gpus", "1", "--config", "3", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 1000.0 and d["config"]["finite"] is True
+    assert "flux_multi" in d["config"]["parallelism"] and "ncclAllGather" in d["config"]["parallelism"]
+    assert d["multi_info"]["devices"] == 1 and d["multi_info"]["rccl_version"] >= 20000
+    b = d["step_breakdown_ms"]
+    assert b["render"] > 0 and b["frame_call"] >= b["render"] and b["all_gather"] >= 0
