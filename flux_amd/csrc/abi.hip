@@ -13,7 +13,10 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <algorithm>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/flux_abi.h"
@@ -367,36 +370,57 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
                     frec_p.size() * sizeof(flux::DevHitRec));
 
     // extension: meshes -> triangle records (hit order: after all shapes) + BVH
-    std::vector<flux::DevTri> tris;
+    std::vector<flux::DevTri> tris((size_t)total_tris);
     std::vector<flux::DevNode> nodes;
-    tris.reserve((size_t)total_tris);
-    for (uint64_t m = 0; m < scene->num_meshes; m++) {
-        const flux_mesh &me = scene->meshes[m];
-        fill_material(mats[ns + (size_t)m], me.material);
-        for (uint64_t k = 0; k < me.num_triangles; k++) {
-            const double *a = me.vertices + 3 * (size_t)me.indices[3 * k];
-            const double *b = me.vertices + 3 * (size_t)me.indices[3 * k + 1];
-            const double *d = me.vertices + 3 * (size_t)me.indices[3 * k + 2];
-            flux::DevTri t;
-            std::memset(&t, 0, sizeof(t));
-            t.v0x = a[0]; t.v0y = a[1]; t.v0z = a[2];
-            t.e1x = b[0] - a[0]; t.e1y = b[1] - a[1]; t.e1z = b[2] - a[2];
-            t.e2x = d[0] - a[0]; t.e2y = d[1] - a[1]; t.e2z = d[2] - a[2];
-            const double e1[3] = {t.e1x, t.e1y, t.e1z}, e2[3] = {t.e2x, t.e2y, t.e2z};
-            double nn[3], nu[3];
-            cross3(e1, e2, nn);
-            if (nn[0] == 0.0 && nn[1] == 0.0 && nn[2] == 0.0) {
-                // a triangle whose e1 x e2 is exactly zero (repeated or exactly collinear vertices) has no surface:
-                // clearing the edges makes Moeller-Trumbore's det exactly 0, so it is never hit (and never NaN)
-                t.e1x = t.e1y = t.e1z = t.e2x = t.e2y = t.e2z = 0.0;
-                nu[0] = nu[1] = nu[2] = 0.0;
-            } else {
-                normalize3(nn, nu);
+    {
+        // one record per triangle: edges, the geometric normal (a square root and three divisions each).  A million of them take
+        // tens of milliseconds on one core, so large meshes are dealt to threads by index range (FLUX_BUILD_THREADS, as for the BVH)
+        std::vector<size_t> first((size_t)scene->num_meshes + 1, 0);
+        for (uint64_t m = 0; m < scene->num_meshes; m++) {
+            fill_material(mats[ns + (size_t)m], scene->meshes[m].material);
+            first[(size_t)m + 1] = first[(size_t)m] + (size_t)scene->meshes[m].num_triangles;
+        }
+        auto make = [&](size_t lo, size_t hi) {
+            size_t m = 0;
+            for (size_t g = lo; g < hi; g++) {
+                while (g >= first[m + 1]) m++;
+                const flux_mesh &me = scene->meshes[m];
+                const size_t k = g - first[m];
+                const double *a = me.vertices + 3 * (size_t)me.indices[3 * k];
+                const double *b = me.vertices + 3 * (size_t)me.indices[3 * k + 1];
+                const double *d = me.vertices + 3 * (size_t)me.indices[3 * k + 2];
+                flux::DevTri t;
+                std::memset(&t, 0, sizeof(t));
+                t.v0x = a[0]; t.v0y = a[1]; t.v0z = a[2];
+                t.e1x = b[0] - a[0]; t.e1y = b[1] - a[1]; t.e1z = b[2] - a[2];
+                t.e2x = d[0] - a[0]; t.e2y = d[1] - a[1]; t.e2z = d[2] - a[2];
+                const double e1[3] = {t.e1x, t.e1y, t.e1z}, e2[3] = {t.e2x, t.e2y, t.e2z};
+                double nn[3], nu[3];
+                cross3(e1, e2, nn);
+                if (nn[0] == 0.0 && nn[1] == 0.0 && nn[2] == 0.0) {
+                    // a triangle whose e1 x e2 is exactly zero (repeated or exactly collinear vertices) has no surface:
+                    // clearing the edges makes Moeller-Trumbore's det exactly 0, so it is never hit (and never NaN)
+                    t.e1x = t.e1y = t.e1z = t.e2x = t.e2y = t.e2z = 0.0;
+                    nu[0] = nu[1] = nu[2] = 0.0;
+                } else {
+                    normalize3(nn, nu);
+                }
+                t.nx = nu[0]; t.ny = nu[1]; t.nz = nu[2];
+                t.id = (int32_t)(ns + g);
+                t.mat = (int32_t)(ns + m);
+                tris[g] = t;
             }
-            t.nx = nu[0]; t.ny = nu[1]; t.nz = nu[2];
-            t.id = (int32_t)(ns + tris.size());
-            t.mat = (int32_t)(ns + m);
-            tris.push_back(t);
+        };
+        unsigned threads = std::thread::hardware_concurrency();
+        if (const char *env = std::getenv("FLUX_BUILD_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
+        threads = std::min(std::max(threads, 1u), 16u);
+        const size_t n = tris.size();
+        if (threads > 1 && n >= 65536) {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < threads; t++) pool.emplace_back(make, n * t / threads, n * (t + 1) / threads);
+            for (std::thread &t : pool) t.join();
+        } else {
+            make(0, n);
         }
     }
     // the traversal addresses node and triangle records by 32-bit byte offsets from their bases (render_body.inc)

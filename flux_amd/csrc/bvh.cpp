@@ -8,11 +8,14 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <functional>
 #include <limits>
+#include <thread>
 
 #ifndef FLUX_BVH_BINS
 #define FLUX_BVH_BINS 16
@@ -51,14 +54,18 @@ struct Box {
     }
 };
 
+// The builder partitions the primitives THEMSELVES, not an index array over them: a split then streams its range (and the lower
+// levels, whose ranges fit a cache, never leave it), where `prims[order[k]]` was a cache miss per triangle per level -- the 1 M-triangle
+// build was bound by exactly that (round 6).  The permutation is the same: std::partition / std::nth_element move elements by position,
+// whatever their size.
 struct Prim {
     Box box;
     double c[3];
+    uint32_t id;  // the triangle's index in the caller's array
 };
 
 struct Builder {
-    const std::vector<Prim> &prims;
-    std::vector<uint32_t> order;
+    std::vector<Prim> &prims;  // shared by all builders of one build: each partitions its own, disjoint range
     std::vector<DevNode> &nodes;
     double pad;
     BvhInfo &info;
@@ -89,16 +96,16 @@ struct Builder {
     Box range_box(uint32_t b, uint32_t e) const {
         Box r;
         r.reset();
-        for (uint32_t k = b; k < e; k++) r.grow(prims[order[k]].box);
+        for (uint32_t k = b; k < e; k++) r.grow(prims[k].box);
         return r;
     }
 
-    // Chooses a split position in (b,e); partitions order[b,e) accordingly.
+    // Chooses a split position in (b,e); partitions prims[b,e) accordingly.
     uint32_t split(uint32_t b, uint32_t e, int depth) {
         const uint32_t n = e - b;
         Box cb;
         cb.reset();
-        for (uint32_t k = b; k < e; k++) cb.grow(prims[order[k]].c);
+        for (uint32_t k = b; k < e; k++) cb.grow(prims[k].c);
         int best_axis = -1, best_bin = -1;
         double best_cost = std::numeric_limits<double>::infinity();
         constexpr int NB = FLUX_BVH_BINS;
@@ -115,7 +122,7 @@ struct Builder {
                 }
                 const double k1 = NB * (1.0 - 1e-12) / ext;
                 for (uint32_t k = b; k < e; k++) {
-                    const Prim &p = prims[order[k]];
+                    const Prim &p = prims[k];
                     int bin = (int)((p.c[a] - cb.lo[a]) * k1);
                     bin = std::min(std::max(bin, 0), NB - 1);
                     bb[bin].grow(p.box);
@@ -155,12 +162,12 @@ struct Builder {
             const int a = best_axis;
             const double ext = cb.hi[a] - cb.lo[a];
             const double k1 = NB * (1.0 - 1e-12) / ext;
-            auto mid = std::partition(order.begin() + b, order.begin() + e, [&](uint32_t id) {
-                int bin = (int)((prims[id].c[a] - cb.lo[a]) * k1);
+            auto mid = std::partition(prims.begin() + b, prims.begin() + e, [&](const Prim &p) {
+                int bin = (int)((p.c[a] - cb.lo[a]) * k1);
                 bin = std::min(std::max(bin, 0), NB - 1);
                 return bin <= best_bin;
             });
-            uint32_t m = (uint32_t)(mid - order.begin());
+            uint32_t m = (uint32_t)(mid - prims.begin());
             if (m > b && m < e) return m;
         }
         // median split on the widest centroid axis (also the depth-bounding fallback)
@@ -168,20 +175,36 @@ struct Builder {
         for (int k = 1; k < 3; k++)
             if (cb.hi[k] - cb.lo[k] > cb.hi[a] - cb.lo[a]) a = k;
         const uint32_t m = b + n / 2;
-        std::nth_element(order.begin() + b, order.begin() + m, order.begin() + e, [&](uint32_t x, uint32_t y) {
-            return prims[x].c[a] < prims[y].c[a] || (prims[x].c[a] == prims[y].c[a] && x < y);
+        std::nth_element(prims.begin() + b, prims.begin() + m, prims.begin() + e, [&](const Prim &x, const Prim &y) {
+            return x.c[a] < y.c[a] || (x.c[a] == y.c[a] && x.id < y.id);
         });
         return m;
     }
 
-    // Builds the subtree over order[b,e) (more than one leaf's worth); returns its node index.
-    int32_t build_inner(uint32_t b, uint32_t e, int depth) {
+    // Builds the subtree over prims[b,e) (more than one leaf's worth); returns its node index.
+    // fork > 0 (large meshes, build_bvh): the LEFT child's subtree is built by a thread of its own -- with its own node vector and
+    // statistics, appended afterwards -- while this thread goes on with the right one, both with fork - 1: level k of the tree is then
+    // 2^k concurrent builders over disjoint ranges of `prims`, and the serial part of the build is the root's split, not the top five
+    // or six levels.  The tree does not depend on it (a split sees its own range only; build_bvh renumbers the nodes breadth-first).
+    int32_t build_inner(uint32_t b, uint32_t e, int depth, int fork = 0) {
         const int32_t me = (int32_t)nodes.size();
         nodes.emplace_back();
         info.max_depth = std::max<uint64_t>(info.max_depth, (uint64_t)depth + 1);
         const uint32_t m = split(b, e, depth);
         const uint32_t rb[2] = {b, m}, re[2] = {m, e};
-        for (int side = 0; side < 2; side++) {
+        std::thread left;
+        std::vector<DevNode> left_nodes;
+        BvhInfo left_info;
+        Box left_box;
+        const bool forked = fork > 0 && (m - b) >= 4096u && (m - b) > (uint32_t)kBvhLeafSize && (e - m) > (uint32_t)kBvhLeafSize;
+        if (forked)
+            left = std::thread([&, this] {
+                Builder L{prims, left_nodes, pad, left_info};
+                left_box = L.range_box(b, m);
+                left_nodes.reserve((m - b) / 2 + 4);
+                L.build_inner(b, m, depth + 1, fork - 1);
+            });
+        for (int side = forked ? 1 : 0; side < 2; side++) {
             const uint32_t cnt = re[side] - rb[side];
             const Box bx = range_box(rb[side], re[side]);
             int32_t link, count = 0;
@@ -190,7 +213,7 @@ struct Builder {
                 count = (int32_t)cnt;
                 info.max_leaf = std::max<uint64_t>(info.max_leaf, cnt);
             } else {
-                link = build_inner(rb[side], re[side], depth + 1);
+                link = build_inner(rb[side], re[side], depth + 1, forked ? fork - 1 : fork);
             }
             DevNode &N = nodes[me];  // re-fetch: the vector may have grown
             if (side == 0) {
@@ -202,6 +225,21 @@ struct Builder {
                 N.child1 = link;
                 N.count1 = count;
             }
+        }
+        if (forked) {
+            left.join();
+            const int32_t off = (int32_t)nodes.size();
+            for (DevNode N : left_nodes) {
+                if (N.child0 >= 0) N.child0 += off;
+                if (N.child1 >= 0) N.child1 += off;
+                nodes.push_back(N);
+            }
+            DevNode &N = nodes[me];
+            store_box(N.lo0, N.hi0, left_box);
+            N.child0 = off;  // the subtree's root is its first node
+            N.count0 = 0;
+            info.max_depth = std::max(info.max_depth, left_info.max_depth);
+            info.max_leaf = std::max(info.max_leaf, left_info.max_leaf);
         }
         return me;
     }
@@ -227,6 +265,7 @@ void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &
         p.box.reset();
         for (int j = 0; j < 3; j++) p.box.grow(v[j]);
         for (int a = 0; a < 3; a++) p.c[a] = 0.5 * (p.box.lo[a] + p.box.hi[a]);
+        p.id = (uint32_t)k;
         all.grow(p.box);
     }
     double diag = 0.0;
@@ -237,10 +276,18 @@ void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &
     // far below anything visible in traversal cost
     const double pad = 1e-7 * std::max(std::max(diag, mag), 1e-30);
 
-    Builder B{prims, {}, nodes, pad, info};
-    B.order.resize(tris.size());
-    for (size_t k = 0; k < tris.size(); k++) B.order[k] = (uint32_t)k;
+    Builder B{prims, nodes, pad, info};
     nodes.reserve(tris.size() / 2 + 4);
+    // Large meshes are built by several threads (build_inner's fork; FLUX_BUILD_THREADS, default: the hardware's, at most 16): the tree,
+    // hence everything that follows from it, is THE SAME as the one-thread build's (tests/bvh_selftest.cpp compares them bit for bit).
+    // 1 M triangles on the GPU box's host: 420 ms with one thread (DESIGN.md "Context creation").
+    unsigned threads = std::thread::hardware_concurrency();
+    if (const char *env = std::getenv("FLUX_BUILD_THREADS")) threads = (unsigned)std::max(1, std::atoi(env));
+    threads = std::min(std::max(threads, 1u), 16u);
+    int fork = 0;
+    if (tris.size() >= 65536)
+        while ((1u << fork) < 2u * threads && fork < 6) fork++;  // about two leaf builders per thread (splits are not exactly even)
+    if (threads <= 1) fork = 0;
     if (tris.size() <= (size_t)kBvhLeafSize) {
         nodes.emplace_back();
         DevNode &N = nodes[0];
@@ -254,7 +301,7 @@ void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &
         info.max_depth = 1;
         info.max_leaf = tris.size();
     } else {
-        B.build_inner(0, (uint32_t)tris.size(), 0);
+        B.build_inner(0, (uint32_t)tris.size(), 0, fork);
     }
     // Relabel the nodes breadth-first with siblings adjacent (built depth-first: child0 = parent + 1, child1
     // far away): the two children of a node then share one 128-B line, and the top of the tree -- touched by
@@ -280,7 +327,7 @@ void build_bvh(std::vector<DevTri> &tris, std::vector<DevNode> &nodes, BvhInfo &
         nodes.swap(re);
     }
     std::vector<DevTri> sorted(tris.size());
-    for (size_t k = 0; k < tris.size(); k++) sorted[k] = tris[B.order[k]];
+    for (size_t k = 0; k < tris.size(); k++) sorted[k] = tris[prims[k].id];
     tris.swap(sorted);
     info.nodes = nodes.size();
     info.mag = mag;

@@ -284,6 +284,31 @@ int main() {
         for (size_t k = 0; k < t.size(); k++) t[k].id = (int)k + 1;
         check_mesh("300 coincident triangles", t);
     }
+    {   // round 6: meshes of 65 536 triangles and more are built by worker threads below a serial top (bvh.cpp build_bvh): the tree,
+        // the triangle order and everything derived from them must be THE SAME as the one-thread build's, bit for bit
+        const std::vector<DevTri> mesh = grid(300, 200, o0, 1.0);  // 120 000 triangles
+        std::vector<DevNode> nodes_ref;
+        std::vector<DevTri> tris_ref;
+        for (const char *threads : {"1", "2", "5", "16"}) {
+            setenv("FLUX_BUILD_THREADS", threads, 1);
+            std::vector<DevTri> t = mesh;
+            std::vector<DevNode> nodes;
+            BvhInfo info;
+            build_bvh(t, nodes, info);
+            if (nodes_ref.empty()) {
+                nodes_ref = nodes;
+                tris_ref = t;
+                continue;
+            }
+            CHECK(nodes.size() == nodes_ref.size() && std::memcmp(nodes.data(), nodes_ref.data(), nodes.size() * sizeof(DevNode)) == 0,
+                  "the %s-thread build's nodes differ from the one-thread build's", threads);
+            CHECK(t.size() == tris_ref.size() && std::memcmp(t.data(), tris_ref.data(), t.size() * sizeof(DevTri)) == 0,
+                  "the %s-thread build's triangle order differs from the one-thread build's", threads);
+        }
+        unsetenv("FLUX_BUILD_THREADS");
+        check_mesh("grid 300x200 (threaded build)", mesh);
+        if (!fails) std::printf("ok threaded build equals the serial build\n");
+    }
     std::printf(fails ? "FAILED (%d)\n" : "all ok\n", fails);
     return fails ? 1 : 0;
 }

@@ -10,10 +10,12 @@ from conftest import ROOT
 
 def test_bvh_builder_invariants(tmp_path):
     exe = str(tmp_path / "bvh_selftest")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "bvh_selftest.cpp"),
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "bvh_selftest.cpp"),
                     os.path.join(ROOT, "flux_amd", "csrc", "bvh.cpp")], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-3000:]
     assert "all ok" in out.stdout
-    for name in ("one triangle", "soup 1000", "grid 200x100", "grid 40x30 at 1e6", "300 coincident triangles"):
+    for name in ("one triangle", "soup 1000", "grid 200x100", "grid 40x30 at 1e6", "300 coincident triangles",
+                 "grid 300x200 (threaded build)"):
         assert f"ok {name}" in out.stdout
+    assert "ok threaded build equals the serial build" in out.stdout
