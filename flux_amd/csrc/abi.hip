@@ -649,6 +649,8 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
             }
         }
     }
+    rp.t_min = flux::kTMin;
+    rp.env_deep = -(4.0 * flux::kTMin) * rp.env_radius;  // (the kernels' own expression, evaluated once)
     for (const flux::DevScanSphere &sp : fsph)
         if (!(std::fabs(sp.px) < 1e3 && std::fabs(sp.py) < 1e3 && std::fabs(sp.pz) < 1e3 && sp.rr < 1e6)) rp.self_skip = 0;
     rp.n_sph = (int32_t)fsph.size();

@@ -209,6 +209,9 @@ struct RenderParams {
     // far?" on squared quantities and takes no square root (render_body.inc scan_shapes_fast<true>); env_radius = its radius
     int32_t env_short, pad_env;
     double env_radius;
+    // kTMin (constants.rs:4) and -(4 kTMin) env_radius (the environment shortcut's "origin well inside" bound), as kernel arguments: held in a
+    // scalar register pair through a pass, where the literals were two scalar moves at every use (round 6)
+    double t_min, env_deep;
     // split kernel: the primary ray's per-frame and per-pixel constants, read with scalar loads in the ray-generation step instead of
     // living in scalar registers across the pass loop: focal * (Wx, Wy, Wz); pxc[x] = x - half_w, pxc[img_w + row] = (img_h - row) - half_h
     double fwx, fwy, fwz;

@@ -35,10 +35,11 @@ __device__ __forceinline__ double frsqrt(double x) {
 
 // sqrt(x), x >= 0; sqrt(0) = 0 exactly.  The tiny NEGATIVES that 1 - c*c or a discriminant can round to are taken as 0:
 // unclamped, a negative x would run the iteration with g = x*y0 hugely negative and overflow to NaN, and one NaN sample
-// poisons a pixel's whole sum.  (The seed is taken of max(x, 1e-300) so that it stays finite.)
+// poisons a pixel's whole sum.  (The seed is taken of max(x, denorm_min) so that it stays finite: 0 * rsq(denorm_min) = 0.)
 __device__ __forceinline__ double fsqrt(double x) {
     x = __builtin_fmax(x, 0.0);
-    const double xs = __builtin_fmax(x, 1e-300);
+    const double xs = __builtin_fmax(x, 4.9406564584124654e-324);  // the smallest denormal: an INLINE constant of the instruction (integer 1),
+                                                                   // where 1e-300 was two scalar moves per evaluation; rsq of it is finite
     const double y0 = __builtin_amdgcn_rsq(xs);
     double g = x * y0;
     double h = 0.5 * y0;
