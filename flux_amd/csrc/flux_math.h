@@ -38,9 +38,9 @@ __device__ __forceinline__ double frsqrt(double x) {
 // poisons a pixel's whole sum.  (The seed is taken of max(x, denorm_min) so that it stays finite: 0 * rsq(denorm_min) = 0.)
 __device__ __forceinline__ double fsqrt(double x) {
     x = __builtin_fmax(x, 0.0);
-    const double xs = __builtin_fmax(x, 4.9406564584124654e-324);  // the smallest denormal: an INLINE constant of the instruction (integer 1),
-                                                                   // where 1e-300 was two scalar moves per evaluation; rsq of it is finite
-    const double y0 = __builtin_amdgcn_rsq(xs);
+    // the seed of x + denorm_min (an INLINE constant of the instruction: the integer 1): x itself for every normal x, finite for x = 0
+    // (until round 6: max(x, 1e-300) -- two scalar moves for the literal and a second maximum)
+    const double y0 = __builtin_amdgcn_rsq(x + 4.9406564584124654e-324);
     double g = x * y0;
     double h = 0.5 * y0;
     const double r = ffma(-h, g, 0.5);
@@ -59,6 +59,21 @@ __device__ __forceinline__ double fdiv(double a, double b) {
     const double q = a * r;
     const double rem = ffma(-q, b, a);
     return ffma(rem, r, q);
+}
+
+// sqrt(x) for a caller that KNOWS x >= 0 (a discriminant behind its own `dq >= 0` test): the same iteration without the clamp of
+// negative inputs (and without the canonicalising v_max the compiler puts in front of it): two instructions less, the same bits.
+__device__ __forceinline__ double fsqrt_nonneg(double x) {
+    // the seed of x + denorm_min: x itself, exactly, for every normal x; finite for x = 0 (0 * rsq(denorm_min) = 0); one addition
+    // where max(x, denorm_min) is two instructions (the compiler canonicalises a maximum's operand first)
+    const double y0 = __builtin_amdgcn_rsq(x + 4.9406564584124654e-324);
+    double g = x * y0;
+    double h = 0.5 * y0;
+    const double r = ffma(-h, g, 0.5);
+    g = ffma(g, r, g);
+    h = ffma(h, r, h);
+    const double d = ffma(-g, g, x);
+    return ffma(d, h, g);
 }
 
 template <int N>
@@ -92,8 +107,10 @@ __device__ __forceinline__ double fexp2(double t) {
 }
 
 // fexp2 with the polynomial's coefficients in memory (flux_math_coeffs.h poly_exp2_tab)
+// (no clamp of t: the one caller's argument is log2(1 - y) / (e + 1) of a TABULATED sample -- flog2 returns a finite value for every input,
+// zero included (see there), and |log2| of a double is below 1100, so the bound of fexp2 cannot bind; the instruction and its 64-bit
+// literal went in round 6)
 __device__ __forceinline__ double fexp2_tab(double t, const double *c) {
-    t = __builtin_fmax(t, -1100.0);
     const double n = __builtin_rint(t);
     const double f = t - n;
     const double p = poly_exp2_tab(f, c);
