@@ -651,6 +651,29 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     }
     rp.t_min = flux::kTMin;
     rp.env_deep = -(4.0 * flux::kTMin) * rp.env_radius;  // (the kernels' own expression, evaluated once)
+    rp.env_px = rp.env_py = rp.env_pz = rp.env_rr = 0.0;
+    if (n_uni == 1) {
+        const flux::DevScanSphere &es = fsph[uni_idx[0]];
+        rp.env_px = es.px; rp.env_py = es.py; rp.env_pz = es.pz; rp.env_rr = es.rr;
+    }
+    {   // the filter's group walk for at most 32 spheres (render_body.inc sphere_filter32: the same arithmetic, done once)
+        rp.f32_half = nullptr;
+        rp.f32_top = rp.fsph32;
+        rp.f32_groups = 0;
+        rp.f32_valid = fsph.size() >= 32 ? 0xffffffffu : (1u << fsph.size()) - 1u;
+        if (rp.fsph32 != nullptr && fsph.size() <= 32) {
+            int pairs = ((int)fsph.size() + 1) >> 1;
+            const int rem = pairs & 3;
+            if (rem == 1 || rem == 2) {
+                rp.f32_half = rp.fsph32 + (pairs - rem);
+                pairs -= rem;
+            } else if (rem == 3) {
+                pairs += 1;  // its fourth pair is padding (zeros)
+            }
+            rp.f32_groups = pairs / 4;
+            rp.f32_top = rp.fsph32 + pairs;
+        }
+    }
     for (const flux::DevScanSphere &sp : fsph)
         if (!(std::fabs(sp.px) < 1e3 && std::fabs(sp.py) < 1e3 && std::fabs(sp.pz) < 1e3 && sp.rr < 1e6)) rp.self_skip = 0;
     rp.n_sph = (int32_t)fsph.size();

@@ -212,6 +212,15 @@ struct RenderParams {
     // kTMin (constants.rs:4) and -(4 kTMin) env_radius (the environment shortcut's "origin well inside" bound), as kernel arguments: held in a
     // scalar register pair through a pass, where the literals were two scalar moves at every use (round 6)
     double t_min, env_deep;
+    // the environment sphere's scan record (fsph[uni_idx[0]] when n_uni == 1) as kernel arguments: one scalar load where the record's
+    // address was a load of the index, four scalar instructions and a dependent load, every pass
+    double env_px, env_py, env_pz, env_rr;
+    // the f32 filter's walk over a scene of at most 32 spheres (sphere_filter32_laid_out), laid out on the host: the half group of one
+    // or two pairs past the full groups (or nullptr), one past the last full group of four pairs, the number of full groups --
+    // per pass the kernel formed all three from n_sph (two dozen scalar instructions)
+    const DevScanSphere32 *f32_half, *f32_top;
+    int32_t f32_groups;
+    uint32_t f32_valid;  // bits 0 .. n_sph - 1
     // split kernel: the primary ray's per-frame and per-pixel constants, read with scalar loads in the ray-generation step instead of
     // living in scalar registers across the pass loop: focal * (Wx, Wy, Wz); pxc[x] = x - half_w, pxc[img_w + row] = (img_h - row) - half_h
     double fwx, fwy, fwz;
