@@ -652,6 +652,7 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
     rp.t_min = flux::kTMin;
     rp.env_deep = -(4.0 * flux::kTMin) * rp.env_radius;  // (the kernels' own expression, evaluated once)
     rp.env_px = rp.env_py = rp.env_pz = rp.env_rr = 0.0;
+    rp.env_eps = 1e-9;
     if (n_uni == 1) {
         const flux::DevScanSphere &es = fsph[uni_idx[0]];
         rp.env_px = es.px; rp.env_py = es.py; rp.env_pz = es.pz; rp.env_rr = es.rr;

@@ -215,6 +215,7 @@ struct RenderParams {
     // the environment sphere's scan record (fsph[uni_idx[0]] when n_uni == 1) as kernel arguments: one scalar load where the record's
     // address was a load of the index, four scalar instructions and a dependent load, every pass
     double env_px, env_py, env_pz, env_rr;
+    double env_eps;  // 1e-9: the relative width of the shortcut's "too close to call" band
     // the f32 filter's walk over a scene of at most 32 spheres (sphere_filter32_laid_out), laid out on the host: the half group of one
     // or two pairs past the full groups (or nullptr), one past the last full group of four pairs, the number of full groups --
     // per pass the kernel formed all three from n_sph (two dozen scalar instructions)
