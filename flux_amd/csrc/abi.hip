@@ -328,9 +328,9 @@ int flux_ctx_create_sets(const flux_scene_desc *scene, const flux_job_cfg *cfg, 
         float f = (float)ppr;
         if ((double)f > ppr) f = std::nextafterf(f, -INFINITY);  // rounded down: the bias is never reduced
         flux::DevScanSphere32 &d = fsph32[k / 2];
-        d.px[k & 1] = (float)sp.px;
-        d.py[k & 1] = (float)sp.py;
-        d.pz[k & 1] = (float)sp.pz;
+        d.px[k & 1] = -(float)sp.px;  // the NEGATED centre (flux_device.h DevScanSphere32)
+        d.py[k & 1] = -(float)sp.py;
+        d.pz[k & 1] = -(float)sp.pz;
         d.ppr[k & 1] = f;
         if ((n_uni > 0 && uni_idx[0] == (int)k) || (n_uni > 1 && uni_idx[1] == (int)k)) {
             d.px[k & 1] = d.py[k & 1] = d.pz[k & 1] = 0.0f;

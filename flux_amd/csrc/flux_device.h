@@ -94,7 +94,7 @@ static_assert(sizeof(DevScanSphere) == 32, "DevScanSphere layout");
 // floats per lane at the issue cost of one f64 instruction) tests two spheres; a missing partner is all zeros.
 typedef float flux_f2 __attribute__((ext_vector_type(2)));
 struct DevScanSphere32 {  // 32 B per pair: four pairs (8 spheres) per 2 x s_load_dwordx16
-    flux_f2 px, py, pz, ppr;
+    flux_f2 px, py, pz, ppr;  // (px, py, pz) = MINUS the centre: hb = o.u + (-p).u, c = o.o + (-p).(2 o) + ppr, the ray's side un-negated
 };
 static_assert(sizeof(DevScanSphere32) == 32, "DevScanSphere32 layout");
 struct DevScanPlane {   // 64 B
