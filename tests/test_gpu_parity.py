@@ -601,6 +601,60 @@ def test_split_kernel_serves_scenes_with_many_planes(flux, oracle_mod, demo1):
             assert np.isfinite(r.render_frame()).all()
 
 
+def test_filter_walk_and_first_plane_for_every_scene_shape(flux, oracle_mod, demo1):
+    """Round 6 moved two pieces of per-pass arithmetic out of the kernels: the f32 filter's walk over a scene of at most 32 spheres
+    (half group / full groups / valid-bit mask: abi.hip lays them out, `sphere_filter32_laid_out` follows them) and the first plane of
+    the scan (peeled: one compare and one select).  Every remainder of the pair groups -- 1 ... 34 spheres, the last two beyond the
+    one-group instantiation -- and 0 / 1 / 3 planes must meet the oracle with identical path statistics, in the split kernel (256 spp)
+    and in the refill kernel; with and without an environment sphere (the usual-scene instantiation needs one)."""
+    import copy
+    rng = np.random.default_rng(11)
+    base = copy.deepcopy(small_scene(demo1, 32, 24))
+    env = base.shapes[0]  # the inverted environment sphere
+
+    def scene(n_sph, n_pln, with_env):
+        sd = copy.deepcopy(base)
+        shapes = [env] if with_env else []
+        while len(shapes) < n_sph:
+            k = len(shapes)
+            m = (flux.MatteData((0.6, 0.5, 0.4), (0, 0, 0), 0.8) if k % 4 == 0 else
+                 flux.GlossyReflectiveData(0.7, (0.9, 0.8, 0.9), float([10.0, 100.0, 1e4][k % 3])) if k % 4 == 1 else
+                 flux.ReflectiveData(0.8, (0.9, 0.9, 1.0)) if k % 4 == 2 else
+                 flux.EmissiveData((1.0, 0.9, 0.8), 1.5))
+            shapes.append(flux.SphereData((float(rng.uniform(-5, 5)), float(rng.uniform(0.2, 3.0)), float(rng.uniform(-2, 10))),
+                                          float(rng.uniform(0.2, 0.8)), m, False))
+        for k in range(n_pln):
+            n = np.array([rng.uniform(-0.2, 0.2), 1.0, rng.uniform(-0.2, 0.2)])
+            n /= np.linalg.norm(n)
+            shapes.append(flux.PlaneData((0.0, float(-0.1 - 0.4 * k), 0.0), tuple(float(x) for x in n),
+                                         flux.MatteData((0.5, 0.5, 0.5), (1, 1, 1), 1.0)))
+        sd.shapes = shapes
+        return sd
+
+    cfg = flux.JobConfiguration(16, 5, 50)  # 256 spp: four waves' worth, the split kernel's range
+    cases = [(n, 1, True) for n in (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 15, 16, 17, 23, 24, 25, 31, 32, 33, 34)]
+    cases += [(6, 0, True), (6, 3, True), (13, 3, True), (5, 1, False), (8, 0, False), (12, 2, False)]
+    for n_sph, n_pln, with_env in cases:
+        sd = scene(n_sph, n_pln, with_env)
+        o = oracle_mod.Oracle(sd, cfg, seed=9)
+        o.stats(reset=True)
+        want = o.render_frame(threads=8)
+        ost = o.stats()
+        o.close()
+        with flux.Renderer(sd, cfg, seed=9) as r:
+            assert r.launch_plan()["math"] == flux.MATH_FAST
+            for kern in (flux.KERNEL_DEFAULT, flux.KERNEL_REFILL):
+                r.set_kernel(kern)
+                r.enable_stats(True)
+                r.stats(reset=True)
+                got = r.render_frame()
+                st = r.stats()
+                assert {k: st[k] for k in ost} == ost, (n_sph, n_pln, with_env, kern)
+                assert max_abs_diff(got, want) < TOL_IMAGE, (n_sph, n_pln, with_env, kern)
+                r.enable_stats(False)
+                assert max_abs_diff(r.render_frame(), got) < 1e-12, (n_sph, n_pln, with_env, kern)
+
+
 def test_strict_filter_equals_the_full_scan(flux, demo1, demo2):
     """Round 5: STRICT takes its sphere candidates from FAST's conservative f32 filter (a sphere the filter rejects is a miss
     whatever BoundingBox::hit says, shapes.rs:173-214) and runs box + quadratic exactly as the reference has them for the rest.
