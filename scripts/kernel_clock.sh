@@ -2,10 +2,11 @@
 # usage (GPU box): scripts/kernel_clock.sh <tag> [bench args]  -- the shader clock DURING the render kernel: GRBM_GUI_ACTIVE (summed over the
 # 8 XCDs) / 8 / the kernel's duration from the same pass's kernel trace is not available in one pass, so: cycles from --pmc, time from bench.py's
 # own event timing of the same launch (kernel_ms in its line).
-TAG=${1:-r05}; shift
-REPO=${GRAFT_REPO_ROOT:-$(pwd)}; export TMPDIR=/tmp; cd $REPO
-OUT=$REPO/gpurun_out/clock_$TAG; mkdir -p $OUT
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d $OUT/pmc -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rccl-probe "$@" > $OUT/bench.json 2> $OUT/err.log || { tail -5 $OUT/err.log; exit 1; }
+set -uo pipefail
+TAG=${1:-r05}; shift || true
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}; export TMPDIR=/tmp; cd "$REPO" || exit 1
+OUT="$REPO/gpurun_out/clock_$TAG"; mkdir -p "$OUT" || exit 1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d "$OUT/pmc" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rccl-probe "$@" > "$OUT/bench.json" 2> "$OUT/err.log" || { tail -5 "$OUT/err.log"; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, json, sys
 out = sys.argv[1]
