@@ -11,3 +11,8 @@ g++ -O1 -g -std=c++17 -pthread -fsanitize=thread -o /tmp/flux_host_test_tsan $SR
 cd $REPO
 ASAN_OPTIONS=detect_leaks=1:protect_shadow_gap=0 /tmp/flux_host_test_asan scenes /tmp | tail -1
 /tmp/flux_host_test_tsan scenes /tmp | tail -1
+# the threaded BVH builder (csrc/bvh.cpp, round 6): its self-test -- the 120 000-triangle threaded build against the serial one -- under both
+g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -o /tmp/bvh_selftest_asan tests/bvh_selftest.cpp flux_amd/csrc/bvh.cpp
+g++ -O1 -g -std=c++17 -pthread -fsanitize=thread -o /tmp/bvh_selftest_tsan tests/bvh_selftest.cpp flux_amd/csrc/bvh.cpp
+FLUX_BUILD_THREADS=4 ASAN_OPTIONS=detect_leaks=1 /tmp/bvh_selftest_asan | tail -1
+FLUX_BUILD_THREADS=4 /tmp/bvh_selftest_tsan | tail -1
